@@ -1,0 +1,151 @@
+/*
+ * mpcx.h — C ABI of the batched kinematic-car OCP solver for MI355X (gfx950).
+ *
+ * The reference has no FFI of its own for this path: the seam is the Python
+ * call  generate_controls(ego, sim_cfg)  (reference src/core_solver.py:112),
+ * which builds ONE optimal-control problem and hands it to acados through
+ * four methods (ctor :354, set :496/:499, solve :502, get :511-513).  The
+ * entry points below replace exactly that inner seam, for a whole batch of
+ * independent problems per call.  The host side that packs EgoConfig /
+ * SimConfig objects into the tables declared here lives in
+ * mpc_amd/core_solver.py and mirrors the reference's names and semantics.
+ *
+ * Conventions
+ *  - plain C, no C++ types, no exceptions cross the boundary;
+ *  - every pointer is caller-owned; the library keeps none after return;
+ *  - return value 0 = the CALL succeeded (per-problem outcomes are in
+ *    mpcx_result.status), negative = MPCX_E_* and mpcx_last_error() has text;
+ *  - all floating point is IEEE binary64, all integers int32_t;
+ *  - the library never falls back to a CPU solver: with no usable HIP device
+ *    every compute entry point returns MPCX_E_NODEVICE.
+ */
+#ifndef MPCX_H
+#define MPCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCX_VERSION 100
+
+#define MPCX_NX 5       /* state  [x, y, theta, v, delta]        (core_solver.py:131) */
+#define MPCX_NU 2       /* input  [acceleration, steering rate]  (core_solver.py:132) */
+#define MPCX_MAX_OBS 4  /* circular obstacles per problem        (core_solver.py:332-351) */
+
+/* Problem table: pdata[field * B + b], one column per problem (structure of
+ * arrays, so that lane b of a wavefront reads consecutive addresses). */
+enum {
+    MPCX_F_X0   = 0,   /* 5  start state, heading already wrapped  (core_solver.py:312) */
+    MPCX_F_GOAL = 5,   /* 5  goal state = yref[2:7] = yref_e       (core_solver.py:226-236) */
+    MPCX_F_W    = 10,  /* 7  diag of W: a, steering rate, x, y, theta, v, delta (:183-193) */
+    MPCX_F_WE   = 17,  /* 5  diag of W_e                           (core_solver.py:197-204) */
+    MPCX_F_LBU  = 22,  /* 2  (core_solver.py:262) */
+    MPCX_F_UBU  = 24,  /* 2  (core_solver.py:263) */
+    MPCX_F_LBX  = 26,  /* 5  stages 1..N-1 (core_solver.py:307) */
+    MPCX_F_UBX  = 31,  /* 5  (core_solver.py:308) */
+    MPCX_F_LBXE = 36,  /* 5  terminal box  (core_solver.py:315-321) */
+    MPCX_F_UBXE = 41,  /* 5  (core_solver.py:322-328) */
+    MPCX_F_CG   = 46,  /* 4  corridor rows: C[0][0], C[0][1], C[1][0], C[1][1] (:280-286) */
+    MPCX_F_LG   = 50,  /* 2  (core_solver.py:296) */
+    MPCX_F_UG   = 52,  /* 2  (core_solver.py:297) */
+    MPCX_F_L    = 54,  /* 1  wheelbase (core_solver.py:14,150) */
+    MPCX_F_H    = 55,  /* 1  shooting interval = duration / N (core_solver.py:239) */
+    MPCX_F_LH   = 56,  /* 1  lower bound of every obstacle row (core_solver.py:349) */
+    MPCX_F_UH   = 57,  /* 1  upper bound of every obstacle row (core_solver.py:351) */
+    MPCX_F_OBS  = 58,  /* 3*MPCX_MAX_OBS: ox, oy, (r+margin)^2 per obstacle (:338-340) */
+    MPCX_NFIELDS = 70
+};
+
+typedef struct mpcx_batch {
+    int32_t B;              /* problems in this call                                  */
+    int32_t N;              /* shooting intervals, same for the whole call (:133)     */
+    const double  *pdata;   /* [MPCX_NFIELDS][B]                                      */
+    const int32_t *n_obs;   /* [B], each 0..MPCX_MAX_OBS                              */
+    const double  *xguess;  /* [N+1][5][B] initial state guess (core_solver.py:477-499) */
+} mpcx_batch;
+
+/* Per-problem status, acados numbering as seen by core_solver.py:502-507. */
+enum {
+    MPCX_SUCCESS    = 0,
+    MPCX_NAN        = 1,  /* non-finite residual                         */
+    MPCX_MAXITER    = 2,  /* max_sqp_iter QP solves without convergence  */
+    MPCX_MINSTEP    = 3,  /* reserved (fixed full step never shrinks)    */
+    MPCX_QP_FAILURE = 4   /* interior-point QP: minimum step or NaN      */
+};
+
+typedef struct mpcx_opts {
+    int32_t max_sqp_iter;   /* nlp_solver_max_iter = 200 (core_solver.py:246)        */
+    int32_t max_qp_iter;    /* qp_solver_iter_max  = 50  (core_solver.py:251)        */
+    double  tol_stat, tol_eq, tol_ineq, tol_comp;   /* tol = 1e-3 (core_solver.py:252) */
+    double  qp_tol_stat, qp_tol_eq, qp_tol_ineq, qp_tol_comp;
+    double  lm;             /* levenberg_marquardt = 1e-2 (core_solver.py:247)       */
+    int32_t lm_scale_by_h;  /* 0: add lm as is; 1: add h*lm on stages < N            */
+    int32_t cond_pred_corr; /* conditional Mehrotra corrector on/off                 */
+    double  mu0;            /* initial barrier parameter                             */
+    double  thr0;           /* slack floor of the cold start                         */
+    double  alpha_min;      /* step below this = QP minimum-step failure             */
+    double  lam_min, t_min; /* floors applied after every interior-point update      */
+    int32_t rti;            /* 1: exactly one linearisation + one QP, no test        */
+    int32_t max_obs;        /* largest n_obs[b] of the batch if known, -1 = unknown:
+                               the host entry point then scans n_obs, the device
+                               entry point assumes MPCX_MAX_OBS                      */
+} mpcx_opts;
+
+typedef struct mpcx_result {
+    double  *X;         /* [B][N+1][5] row b is the 'x' array of core_solver.py:521 */
+    double  *U;         /* [B][N][2]   row b is the 'u' array of core_solver.py:522 */
+    int32_t *status;    /* [B]   MPCX_SUCCESS ...                                   */
+    int32_t *sqp_iter;  /* [B]   QP solves performed                                */
+    int32_t *qp_iter;   /* [B]   interior-point iterations, summed over QP solves   */
+    double  *cost;      /* [B]   objective at the returned iterate                  */
+    double  *res;       /* [4][B] stat, eq, ineq, comp residual at the last test    */
+} mpcx_result;
+
+int         mpcx_version(void);
+const char *mpcx_last_error(void);          /* thread-local, never NULL */
+void        mpcx_opts_default(mpcx_opts *o);
+
+/* Number of HIP devices this process can see (0 if none / no driver). */
+int mpcx_device_count(void);
+
+/*
+ * Replaces AcadosOcpSolver(...) + set + solve + get (core_solver.py:354-513)
+ * for B problems.  Pointers in `in` and `out` are HOST memory; the call
+ * uploads, solves on HIP device `device`, downloads, and returns when the
+ * results are in `out`.
+ */
+int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts,
+                     mpcx_result *out, int device);
+
+/*
+ * Same solve with every pointer in `in`, `out` and `workspace` already in the
+ * memory of the CURRENT HIP device.  Asynchronous: kernels are queued on
+ * `stream` (a hipStream_t, NULL = default stream) and the call returns.
+ * `workspace` must hold mpcx_workspace_bytes(B, N) bytes, 256-byte aligned.
+ */
+size_t mpcx_workspace_bytes(int32_t B, int32_t N);
+int    mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts,
+                               mpcx_result *out, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
+/*
+ * Diagnostic, no counterpart in the reference: sin and cos of n host doubles,
+ * evaluated on device `device` by the same routine the solver's RK4 uses, so
+ * that tests can compare the device arithmetic bit for bit with a CPU program.
+ */
+int mpcx_probe_sincos(const double *x, int32_t n, double *s, double *c, int device);
+
+enum {
+    MPCX_E_BADARG   = -1,
+    MPCX_E_NODEVICE = -2,
+    MPCX_E_HIP      = -3,
+    MPCX_E_NOMEM    = -4
+};
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCX_H */

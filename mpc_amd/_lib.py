@@ -1,0 +1,134 @@
+"""ctypes binding of libmpcx.so (include/mpcx.h).
+
+The library is built in-tree (mpc_amd/csrc/libmpcx.so) by
+``__graft_entry__.build()``.  There is no CPU fallback: if the library is
+missing or no HIP device is usable, solving raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmpcx.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class MpcxBatch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32),
+                ("pdata", C.c_void_p), ("n_obs", C.c_void_p), ("xguess", C.c_void_p)]
+
+
+class MpcxOpts(C.Structure):
+    _fields_ = [("max_sqp_iter", C.c_int32), ("max_qp_iter", C.c_int32),
+                ("tol_stat", C.c_double), ("tol_eq", C.c_double),
+                ("tol_ineq", C.c_double), ("tol_comp", C.c_double),
+                ("qp_tol_stat", C.c_double), ("qp_tol_eq", C.c_double),
+                ("qp_tol_ineq", C.c_double), ("qp_tol_comp", C.c_double),
+                ("lm", C.c_double), ("lm_scale_by_h", C.c_int32),
+                ("cond_pred_corr", C.c_int32),
+                ("mu0", C.c_double), ("thr0", C.c_double), ("alpha_min", C.c_double),
+                ("lam_min", C.c_double), ("t_min", C.c_double),
+                ("rti", C.c_int32), ("max_obs", C.c_int32)]
+
+
+class MpcxResult(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("U", C.c_void_p), ("status", C.c_void_p),
+                ("sqp_iter", C.c_void_p), ("qp_iter", C.c_void_p),
+                ("cost", C.c_void_p), ("res", C.c_void_p)]
+
+
+class MpcxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libmpcx.so and declare its prototypes.  Raises if it is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise MpcxError(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)")
+    lib = C.CDLL(p)
+    lib.mpcx_version.restype = C.c_int
+    lib.mpcx_last_error.restype = C.c_char_p
+    lib.mpcx_opts_default.argtypes = [C.POINTER(MpcxOpts)]
+    lib.mpcx_opts_default.restype = None
+    lib.mpcx_device_count.restype = C.c_int
+    lib.mpcx_solve_batch.argtypes = [C.POINTER(MpcxBatch), C.POINTER(MpcxOpts),
+                                     C.POINTER(MpcxResult), C.c_int]
+    lib.mpcx_solve_batch.restype = C.c_int
+    lib.mpcx_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.mpcx_workspace_bytes.restype = C.c_size_t
+    lib.mpcx_solve_batch_device.argtypes = [C.POINTER(MpcxBatch), C.POINTER(MpcxOpts),
+                                            C.POINTER(MpcxResult), C.c_void_p,
+                                            C.c_size_t, C.c_void_p]
+    lib.mpcx_solve_batch_device.restype = C.c_int
+    lib.mpcx_probe_sincos.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int]
+    lib.mpcx_probe_sincos.restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def default_opts(lib=None):
+    lib = lib or load_library()
+    o = MpcxOpts()
+    lib.mpcx_opts_default(C.byref(o))
+    return o
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        msg = lib.mpcx_last_error()
+        raise MpcxError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def alloc_result(B, N):
+    """Host arrays of one call's outputs, in the layout of mpcx_result."""
+    return {
+        "X": np.empty((B, N + 1, 5), dtype=np.float64),
+        "U": np.empty((B, N, 2), dtype=np.float64),
+        "status": np.empty(B, dtype=np.int32),
+        "sqp_iter": np.empty(B, dtype=np.int32),
+        "qp_iter": np.empty(B, dtype=np.int32),
+        "cost": np.empty(B, dtype=np.float64),
+        "res": np.empty((4, B), dtype=np.float64),
+    }
+
+
+def batch_struct(packed):
+    assert packed.pdata.flags.c_contiguous and packed.pdata.dtype == np.float64
+    assert packed.xguess.flags.c_contiguous and packed.xguess.dtype == np.float64
+    assert packed.n_obs.flags.c_contiguous and packed.n_obs.dtype == np.int32
+    return MpcxBatch(packed.B, packed.N, packed.pdata.ctypes.data,
+                     packed.n_obs.ctypes.data, packed.xguess.ctypes.data)
+
+
+def result_struct(out):
+    return MpcxResult(*(out[k].ctypes.data for k in
+                        ("X", "U", "status", "sqp_iter", "qp_iter", "cost", "res")))
+
+
+def solve_packed(packed, opts=None, device=0):
+    """Solve one PackedBatch on HIP device ``device``; returns the output dict."""
+    lib = load_library()
+    if lib.mpcx_device_count() <= 0:
+        raise MpcxError("no HIP device available (there is no CPU fallback)")
+    opts = opts or default_opts(lib)
+    out = alloc_result(packed.B, packed.N)
+    if packed.B == 0:
+        return out
+    b = batch_struct(packed)
+    r = result_struct(out)
+    _check(lib, lib.mpcx_solve_batch(C.byref(b), C.byref(opts), C.byref(r), int(device)),
+           "mpcx_solve_batch")
+    return out

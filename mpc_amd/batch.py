@@ -1,0 +1,284 @@
+"""Host-side problem data: from (EgoConfig, SimConfig) pairs to the SoA tables
+of include/mpcx.h, and the initial state guess of the reference.
+
+Everything here is the part of reference src/core_solver.py:127-351 and
+:360-499 that runs BEFORE the solver is called: it fixes N, the bounds, the
+corridor rows, the obstacle rows and the per-node guess.  The values must be
+the reference's to the last bit, so scalar code keeps the reference's
+expression order and the vectorised forms use the same IEEE operations
+element-wise.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from .corridor import corridor_cal, corridor_cal_batch
+
+NX = 5
+NU = 2
+MAX_OBS = 4
+
+# field offsets of include/mpcx.h (enum MPCX_F_*)
+F_X0, F_GOAL, F_W, F_WE = 0, 5, 10, 17
+F_LBU, F_UBU, F_LBX, F_UBX, F_LBXE, F_UBXE = 22, 24, 26, 31, 36, 41
+F_CG, F_LG, F_UG, F_L, F_H, F_LH, F_UH, F_OBS = 46, 50, 52, 54, 55, 56, 57, 58
+NFIELDS = 70
+
+# constants the reference hard-codes in generate_controls
+EPS_POS, EPS_ANGLE, EPS_VEL = 1e-1, 1e-2, 1e-2      # core_solver.py:257-259
+XY_MAX = 100.0                                       # core_solver.py:305-306
+G_LOWER = -1e9                                       # core_solver.py:296,301
+H_LOWER, H_UPPER = 0.0, 1e9                          # core_solver.py:349,351
+
+
+def horizon_length(sim_cfg):
+    """N = int(duration / dt), truncation included (reference core_solver.py:133)."""
+    return int(sim_cfg.duration / sim_cfg.dt)
+
+
+@dataclass
+class PackedBatch:
+    """One call's worth of problems, all with the same N."""
+    B: int
+    N: int
+    pdata: np.ndarray    # float64 [NFIELDS, B]
+    n_obs: np.ndarray    # int32 [B]
+    xguess: np.ndarray   # float64 [N+1, 5, B]
+    duration: float = 0.0
+
+    def slice(self, lo, hi):
+        return PackedBatch(hi - lo, self.N,
+                           np.ascontiguousarray(self.pdata[:, lo:hi]),
+                           np.ascontiguousarray(self.n_obs[lo:hi]),
+                           np.ascontiguousarray(self.xguess[:, :, lo:hi]),
+                           self.duration)
+
+
+# ---------------------------------------------------------------------------
+# initial guess, one problem (reference core_solver.py:360-499, verbatim order)
+# ---------------------------------------------------------------------------
+def adjust_point_for_obstacles(ego, x_init, y_init):
+    """Move a guess point off obstacles (reference core_solver.py:360-473).
+
+    If an obstacle straddles the start->goal line the whole line is shifted
+    sideways and the point projected on it; otherwise a point inside an
+    obstacle is pushed radially to its inflated radius.
+    """
+    if ego.obstacles is None:
+        return x_init, y_init
+    x_adj, y_adj = x_init, y_init
+    sx, sy = ego.state_start[0], ego.state_start[1]
+    gx, gy = ego.state_final[0], ego.state_final[1]
+    pdx = gx - sx
+    pdy = gy - sy
+    plen = np.sqrt(pdx**2 + pdy**2)
+    if plen < 1e-6:
+        return x_init, y_init
+    pdx /= plen
+    pdy /= plen
+    ndx = -pdy
+    ndy = pdx
+    path_shift = 0
+    shift_direction = 1
+    for obs in ego.obstacles:
+        ox, oy, orad, margin = obs
+        total_radius = orad + margin + 0.05
+        odx = ox - sx
+        ody = oy - sy
+        projection = odx * pdx + ody * pdy
+        cx = sx + projection * pdx
+        cy = sy + projection * pdy
+        dist_to_path = np.sqrt((cx - ox)**2 + (cy - oy)**2)
+        if dist_to_path < total_radius and 0 <= projection <= plen:
+            point_side = (x_init - sx) * ndx + (y_init - sy) * ndy
+            if point_side < 0:
+                shift_direction = -1          # sticky: never reset (reference :422-423)
+            needed = total_radius - dist_to_path
+            if needed > path_shift:
+                path_shift = needed
+    if path_shift > 0:
+        amount = path_shift + 0.1
+        ssx = sx + shift_direction * ndx * amount
+        ssy = sy + shift_direction * ndy * amount
+        vdx = x_init - ssx
+        vdy = y_init - ssy
+        proj = vdx * pdx + vdy * pdy
+        proj = max(0, min(proj, plen))
+        return ssx + proj * pdx, ssy + proj * pdy
+    for obs in ego.obstacles:
+        ox, oy, orad, margin = obs
+        total_radius = orad + margin + 0.05
+        dx = x_adj - ox
+        dy = y_adj - oy
+        distance = np.sqrt(dx**2 + dy**2)
+        if distance < total_radius:
+            angle = np.arctan2(dy, dx)
+            x_adj = ox + total_radius * np.cos(angle)
+            y_adj = oy + total_radius * np.sin(angle)
+    return x_adj, y_adj
+
+
+def initial_guess(ego, N, corridor=None):
+    """Per-node state guess ``[N+1, 5]`` (reference core_solver.py:477-499)."""
+    if corridor is None:
+        corridor = corridor_cal((ego.state_start[0], ego.state_start[1]),
+                                (ego.state_final[0], ego.state_final[1]),
+                                ego.corridor_width)
+    c1, a1, b1, c2, a2, b2 = corridor
+    out = np.empty((N + 1, NX), dtype=np.float64)
+    s, g = ego.state_start, ego.state_final
+    for i in range(N + 1):
+        t = float(i) / N
+        x_init = s[0] + t * (g[0] - s[0])
+        y_init = s[1] + t * (g[1] - s[1])
+        # the reference's centre line formula assumes c == 1; kept as is (:484-485)
+        y_center = -(a1 * x_init + b1 / 2 + a2 * x_init + b2 / 2) / 2
+        y_init = min(max(y_init, y_center - ego.corridor_width / 2),
+                     y_center + ego.corridor_width / 2)
+        x_init, y_init = adjust_point_for_obstacles(ego, x_init, y_init)
+        theta_init = s[2] + t * (g[2] - s[2])
+        v_init = 1.0 * (1 - t)
+        if i < N:
+            out[i] = (x_init, y_init, theta_init, v_init, 0.0)
+    out[N] = np.asarray(g, dtype=np.float64)          # reference :499
+    return out
+
+
+def initial_guess_batch(start, goal, width, N, a, b1, b2):
+    """Vectorised ``initial_guess`` for problems WITHOUT obstacles.
+
+    start, goal: float64 [B, 5]; width, a, b1, b2: float64 [B].
+    Returns [N+1, 5, B] (the library's layout).  Same operations per element
+    as the scalar loop, so the result is identical to it.
+    """
+    B = start.shape[0]
+    out = np.empty((N + 1, NX, B), dtype=np.float64)
+    half = width / 2
+    for i in range(N):
+        t = float(i) / N
+        x = start[:, 0] + t * (goal[:, 0] - start[:, 0])
+        y = start[:, 1] + t * (goal[:, 1] - start[:, 1])
+        yc = -(a * x + b1 / 2 + a * x + b2 / 2) / 2
+        y = np.minimum(np.maximum(y, yc - half), yc + half)
+        out[i, 0] = x
+        out[i, 1] = y
+        out[i, 2] = start[:, 2] + t * (goal[:, 2] - start[:, 2])
+        out[i, 3] = 1.0 * (1 - t)
+        out[i, 4] = 0.0
+    out[N] = goal.T
+    return out
+
+
+# ---------------------------------------------------------------------------
+# packing
+# ---------------------------------------------------------------------------
+def _ego_fields(ego, N, duration):
+    """One column of the problem table for one EgoConfig."""
+    col = np.zeros(NFIELDS, dtype=np.float64)
+    s = np.asarray(ego.state_start, dtype=np.float64)
+    g = np.asarray(ego.state_final, dtype=np.float64)
+    col[F_X0:F_X0 + 5] = s
+    col[F_GOAL:F_GOAL + 5] = g
+    col[F_W:F_W + 7] = (ego.weight_acceleration, ego.weight_steering_rate,
+                        ego.weight_position_x, ego.weight_position_y,
+                        ego.weight_heading, ego.weight_velocity, ego.weight_steering)
+    col[F_WE:F_WE + 5] = (ego.weight_terminal_position_x, ego.weight_terminal_position_y,
+                          ego.weight_terminal_heading, ego.weight_terminal_velocity,
+                          ego.weight_terminal_steering)
+    col[F_LBU:F_LBU + 2] = (ego.acceleration_min, ego.steering_rate_min)
+    col[F_UBU:F_UBU + 2] = (ego.acceleration_max, ego.steering_rate_max)
+    col[F_LBX:F_LBX + 5] = (-XY_MAX, -XY_MAX, -np.pi, ego.velocity_min, ego.steering_min)
+    col[F_UBX:F_UBX + 5] = (XY_MAX, XY_MAX, np.pi, ego.velocity_max, ego.steering_max)
+    eps = (EPS_POS, EPS_POS, EPS_ANGLE, EPS_VEL, EPS_VEL)
+    for i in range(5):
+        col[F_LBXE + i] = ego.state_final[i] - eps[i]
+        col[F_UBXE + i] = ego.state_final[i] + eps[i]
+    corridor = corridor_cal((ego.state_start[0], ego.state_start[1]),
+                            (ego.state_final[0], ego.state_final[1]),
+                            ego.corridor_width)
+    c1, a1, b1, c2, a2, b2 = corridor
+    col[F_CG:F_CG + 4] = (float(-a1), float(-c1), float(a2), float(c2))
+    col[F_LG:F_LG + 2] = (G_LOWER, G_LOWER)
+    col[F_UG:F_UG + 2] = (float(b1), float(-b2))
+    col[F_L] = ego.L
+    col[F_H] = duration / N
+    col[F_LH] = H_LOWER
+    col[F_UH] = H_UPPER
+    n_obs = 0
+    if ego.obstacles is not None and len(ego.obstacles) > 0:
+        n_obs = len(ego.obstacles)
+        if n_obs > MAX_OBS:
+            raise ValueError(f"at most {MAX_OBS} obstacles per problem, got {n_obs}")
+        for j, (ox, oy, orad, margin) in enumerate(ego.obstacles):
+            col[F_OBS + 3 * j:F_OBS + 3 * j + 3] = (ox, oy, (orad + margin)**2)
+    return col, n_obs, corridor
+
+
+def pack_problems(egos, sim_cfg):
+    """Pack EgoConfig objects that share one SimConfig into a PackedBatch."""
+    N = horizon_length(sim_cfg)
+    if N < 1:
+        raise ValueError("duration / dt must give at least one shooting interval")
+    B = len(egos)
+    pdata = np.zeros((NFIELDS, B), dtype=np.float64)
+    n_obs = np.zeros(B, dtype=np.int32)
+    xguess = np.empty((N + 1, NX, B), dtype=np.float64)
+    for b, ego in enumerate(egos):
+        col, nb, corridor = _ego_fields(ego, N, sim_cfg.duration)
+        pdata[:, b] = col
+        n_obs[b] = nb
+        xguess[:, :, b] = initial_guess(ego, N, corridor)
+    return PackedBatch(B, N, pdata, n_obs, xguess, float(sim_cfg.duration))
+
+
+def normalize_angle_array(angle):
+    """EgoConfig.normalize_angle on an array (reference core_solver.py:59-63)."""
+    return ((angle + np.pi) % (2 * np.pi)) - np.pi
+
+
+def pack_arrays(start, goal, duration, dt=0.1, corridor_width=15.0, L=2.7,
+                velocity=(-3.0, 3.0), acceleration=(-2.0, 2.0), steering=(-0.5, 0.5),
+                steering_rate=(-0.4, 0.4), weights=(100.0, 100.0, 0.0, 0.0, 0.0, 0.0, 0.0),
+                terminal_weights=(100.0, 100.0, 100.0, 10.0, 10.0)):
+    """Vectorised packing of obstacle-free problems that differ only in start
+    and goal state (the synthetic benchmark batch, the grid sweep).
+
+    start, goal: [B, 5]; headings are wrapped exactly as the EgoConfig setters
+    wrap them.  Every other EgoConfig field takes the given common value
+    (defaults = EgoConfig defaults, reference core_solver.py:14-53).
+    """
+    start = np.array(start, dtype=np.float64, copy=True)
+    goal = np.array(goal, dtype=np.float64, copy=True)
+    B = start.shape[0]
+    start[:, 2] = normalize_angle_array(start[:, 2])
+    goal[:, 2] = normalize_angle_array(goal[:, 2])
+    N = int(duration / dt)
+    width = np.full(B, float(corridor_width))
+    c, a, b1, b2 = corridor_cal_batch(start[:, 0], start[:, 1], goal[:, 0], goal[:, 1], width)
+    pdata = np.zeros((NFIELDS, B), dtype=np.float64)
+    pdata[F_X0:F_X0 + 5] = start.T
+    pdata[F_GOAL:F_GOAL + 5] = goal.T
+    pdata[F_W:F_W + 7] = np.asarray(weights, dtype=np.float64)[:, None]
+    pdata[F_WE:F_WE + 5] = np.asarray(terminal_weights, dtype=np.float64)[:, None]
+    pdata[F_LBU] = acceleration[0]
+    pdata[F_LBU + 1] = steering_rate[0]
+    pdata[F_UBU] = acceleration[1]
+    pdata[F_UBU + 1] = steering_rate[1]
+    pdata[F_LBX:F_LBX + 5] = np.array([-XY_MAX, -XY_MAX, -np.pi, velocity[0], steering[0]])[:, None]
+    pdata[F_UBX:F_UBX + 5] = np.array([XY_MAX, XY_MAX, np.pi, velocity[1], steering[1]])[:, None]
+    eps = np.array([EPS_POS, EPS_POS, EPS_ANGLE, EPS_VEL, EPS_VEL])
+    pdata[F_LBXE:F_LBXE + 5] = (goal - eps).T
+    pdata[F_UBXE:F_UBXE + 5] = (goal + eps).T
+    pdata[F_CG + 0] = -a
+    pdata[F_CG + 1] = -c
+    pdata[F_CG + 2] = a
+    pdata[F_CG + 3] = c
+    pdata[F_LG:F_LG + 2] = G_LOWER
+    pdata[F_UG] = b1
+    pdata[F_UG + 1] = -b2
+    pdata[F_L] = L
+    pdata[F_H] = duration / N
+    pdata[F_LH] = H_LOWER
+    pdata[F_UH] = H_UPPER
+    xguess = initial_guess_batch(start, goal, width, N, a, b1, b2)
+    return PackedBatch(B, N, pdata, np.zeros(B, dtype=np.int32), xguess, float(duration))

@@ -1,0 +1,211 @@
+// mpcx_api.hip — the C ABI of include/mpcx.h on top of the kernels.
+//
+// Host code only: argument checks, device buffers, the launch.  There is no
+// CPU solver behind these entry points; without a usable HIP device they
+// return MPCX_E_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mpcx.h"
+#include "mpcx_kernels.h"
+
+namespace {
+
+constexpr int kMaxWaves = 2048;   // persistent 64-lane workgroups per launch (8 per CU on 256 CUs)
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                 \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            return fail(MPCX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));          \
+    } while (0)
+
+int waves_for(int B)
+{
+    int g = (B + 63) / 64;
+    return g < kMaxWaves ? g : kMaxWaves;
+}
+
+int check_call(const mpcx_batch *in, const mpcx_opts *o, const mpcx_result *out)
+{
+    if (!in || !o || !out) return fail(MPCX_E_BADARG, "null argument");
+    if (in->B < 0 || in->N < 1) return fail(MPCX_E_BADARG, "need B >= 0 and N >= 1 (B=%d, N=%d)", in->B, in->N);
+    if (in->B > 0 && (!in->pdata || !in->xguess)) return fail(MPCX_E_BADARG, "null pdata / xguess");
+    if (in->B > 0 && (!out->X || !out->U || !out->status || !out->sqp_iter || !out->qp_iter ||
+                      !out->cost || !out->res))
+        return fail(MPCX_E_BADARG, "null output array");
+    if (o->max_sqp_iter < 0 || o->max_qp_iter < 0) return fail(MPCX_E_BADARG, "negative iteration limit");
+    if (o->max_obs > MPCX_MAX_OBS) return fail(MPCX_E_BADARG, "max_obs %d > %d", o->max_obs, MPCX_MAX_OBS);
+    return 0;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int mpcx_version(void) { return MPCX_VERSION; }
+
+const char *mpcx_last_error(void) { return g_err; }
+
+void mpcx_opts_default(mpcx_opts *o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->max_sqp_iter = 200;
+    o->max_qp_iter = 50;
+    o->tol_stat = o->tol_eq = o->tol_ineq = o->tol_comp = 1e-3;
+    o->qp_tol_stat = o->qp_tol_eq = o->qp_tol_ineq = o->qp_tol_comp = 1e-3;
+    o->lm = 1e-2;
+    o->lm_scale_by_h = 0;
+    o->cond_pred_corr = 1;
+    o->mu0 = 1e1;
+    o->thr0 = 1e-1;
+    o->alpha_min = 1e-8;
+    o->lam_min = 1e-16;
+    o->t_min = 1e-16;
+    o->rti = 0;
+    o->max_obs = -1;
+}
+
+int mpcx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t mpcx_workspace_bytes(int32_t B, int32_t N)
+{
+    if (B <= 0 || N < 1) return 0;
+    return (size_t)waves_for(B) * (size_t)(N + 1) * mpcx_stage_doubles(MPCX_MAX_OBS) * 64 * sizeof(double);
+}
+
+int mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *out,
+                            void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_call(in, opts, out)) return rc;
+    if (in->B == 0) return 0;
+    if (mpcx_device_count() <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
+    const int nh = (opts->max_obs < 0) ? MPCX_MAX_OBS : opts->max_obs;
+    const int n_waves = waves_for(in->B);
+    const size_t need = (size_t)n_waves * (size_t)(in->N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
+    if (!workspace || workspace_bytes < need)
+        return fail(MPCX_E_BADARG, "workspace too small: %zu bytes given, %zu needed", workspace_bytes, need);
+    if ((uintptr_t)workspace % 256 != 0) return fail(MPCX_E_BADARG, "workspace not 256-byte aligned");
+    HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(workspace), n_waves,
+                            static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *out, int device)
+{
+    if (int rc = check_call(in, opts, out)) return rc;
+    if (in->B == 0) return 0;
+    const int ndev = mpcx_device_count();
+    if (ndev <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(MPCX_E_BADARG, "device %d out of range [0, %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    const size_t B = (size_t)in->B, N = (size_t)in->N;
+    mpcx_opts o = *opts;
+    int nh = 0;
+    if (in->n_obs) {
+        for (size_t b = 0; b < B; ++b) {
+            if (in->n_obs[b] < 0 || in->n_obs[b] > MPCX_MAX_OBS)
+                return fail(MPCX_E_BADARG, "n_obs[%zu] = %d outside [0, %d]", b, in->n_obs[b], MPCX_MAX_OBS);
+            if (in->n_obs[b] > nh) nh = in->n_obs[b];
+        }
+    }
+    if (o.max_obs >= 0 && o.max_obs < nh) return fail(MPCX_E_BADARG, "max_obs %d < largest n_obs %d", o.max_obs, nh);
+    o.max_obs = nh;
+
+    const size_t n_pd = (size_t)MPCX_NFIELDS * B, n_xg = (N + 1) * MPCX_NX * B;
+    const size_t n_X = B * (N + 1) * MPCX_NX, n_U = B * N * MPCX_NU;
+    const int n_waves = waves_for(in->B);
+    const size_t ws_bytes = (size_t)n_waves * (N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
+
+    DevBuf d_pd, d_no, d_xg, d_X, d_U, d_st, d_si, d_qi, d_co, d_re, d_ws;
+    if (d_pd.alloc(n_pd * 8) != hipSuccess || d_no.alloc(B * 4) != hipSuccess ||
+        d_xg.alloc(n_xg * 8) != hipSuccess || d_X.alloc(n_X * 8) != hipSuccess ||
+        d_U.alloc(n_U * 8) != hipSuccess || d_st.alloc(B * 4) != hipSuccess ||
+        d_si.alloc(B * 4) != hipSuccess || d_qi.alloc(B * 4) != hipSuccess ||
+        d_co.alloc(B * 8) != hipSuccess || d_re.alloc(4 * B * 8) != hipSuccess ||
+        d_ws.alloc(ws_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(MPCX_E_NOMEM, "device allocation failed (workspace %zu bytes)", ws_bytes);
+    }
+    HIP_TRY(hipMemcpy(d_pd.p, in->pdata, n_pd * 8, hipMemcpyHostToDevice));
+    if (in->n_obs) HIP_TRY(hipMemcpy(d_no.p, in->n_obs, B * 4, hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemset(d_no.p, 0, B * 4));
+    HIP_TRY(hipMemcpy(d_xg.p, in->xguess, n_xg * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_st.p, 0xff, B * 4));
+
+    mpcx_batch din = *in;
+    din.pdata = d_pd.as<double>();
+    din.n_obs = d_no.as<int32_t>();
+    din.xguess = d_xg.as<double>();
+    mpcx_result dout;
+    dout.X = d_X.as<double>();
+    dout.U = d_U.as<double>();
+    dout.status = d_st.as<int32_t>();
+    dout.sqp_iter = d_si.as<int32_t>();
+    dout.qp_iter = d_qi.as<int32_t>();
+    dout.cost = d_co.as<double>();
+    dout.res = d_re.as<double>();
+
+    HIP_TRY(mpcx_launch_sqp(nh, din, o, dout, d_ws.as<double>(), n_waves, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+
+    HIP_TRY(hipMemcpy(out->X, d_X.p, n_X * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->U, d_U.p, n_U * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->status, d_st.p, B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->sqp_iter, d_si.p, B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->qp_iter, d_qi.p, B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->cost, d_co.p, B * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->res, d_re.p, 4 * B * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// arithmetic probe used by the parity tests: sin/cos of n host doubles as the
+// solver computes them on the device
+int mpcx_probe_sincos(const double *x, int32_t n, double *s, double *c, int device)
+{
+    if (!x || !s || !c || n < 0) return fail(MPCX_E_BADARG, "bad probe arguments");
+    if (n == 0) return 0;
+    if (mpcx_device_count() <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf dx, ds, dc;
+    if (dx.alloc((size_t)n * 8) != hipSuccess || ds.alloc((size_t)n * 8) != hipSuccess ||
+        dc.alloc((size_t)n * 8) != hipSuccess)
+        return fail(MPCX_E_NOMEM, "device allocation failed");
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(mpcx_launch_probe(dx.as<double>(), n, ds.as<double>(), dc.as<double>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(s, ds.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c, dc.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,22 @@
+// Internal interface between the C ABI (mpcx_api.hip) and the kernels.
+#ifndef MPCX_KERNELS_H
+#define MPCX_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#include "../../include/mpcx.h"
+
+// doubles of workspace per stage and lane for a kernel built for `nh` obstacle rows
+size_t mpcx_stage_doubles(int nh);
+
+// Launch the fused SQP solve on `n_waves` persistent 64-lane workgroups.  All
+// pointers inside `in` / `out` and `workspace` are device memory; `workspace`
+// holds n_waves * (N+1) * mpcx_stage_doubles(nh) * 64 doubles.
+hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
+                           double *workspace, int n_waves, hipStream_t stream);
+
+// sin/cos exactly as the solver computes them (arithmetic parity tests)
+hipError_t mpcx_launch_probe(const double *xin, int n, double *s, double *c, hipStream_t stream);
+
+#endif
