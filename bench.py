@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: converged OCPs/sec on the 1M random start/goal batch.
+
+One step = one full solve of the rank's batch (N = 50 kinematic-car problems,
+seed 20250310 + rank) by the fused HIP kernel, inputs and outputs resident in
+HBM.  Prints ONE JSON line on rank 0.  Multi-GPU: one process per GPU, each
+solves its own batch (no data-path collective); the only collective is the
+reduction of the counters for the report.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X vector FP64 (datasheet)
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1_000_000, help="problems per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="problems timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mpc_amd import _lib, flops
+    from mpc_amd.synthetic import SEED, synthetic_batch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    lib = _lib.load_library()
+    opts = _lib.default_opts(lib)
+    opts.max_obs = 0
+
+    B = args.batch
+    packed = synthetic_batch(B, seed=SEED + rank)
+    N = packed.N
+
+    # inputs resident in HBM before the timed region
+    d_pd = torch.from_numpy(packed.pdata).to(dev)
+    d_no = torch.from_numpy(packed.n_obs).to(dev)
+    d_xg = torch.from_numpy(packed.xguess).to(dev)
+    d_X = torch.empty((B, N + 1, 5), dtype=torch.float64, device=dev)
+    d_U = torch.empty((B, N, 2), dtype=torch.float64, device=dev)
+    d_st = torch.empty(B, dtype=torch.int32, device=dev)
+    d_si = torch.empty(B, dtype=torch.int32, device=dev)
+    d_qi = torch.empty(B, dtype=torch.int32, device=dev)
+    d_co = torch.empty(B, dtype=torch.float64, device=dev)
+    d_re = torch.empty((4, B), dtype=torch.float64, device=dev)
+    ws_bytes = lib.mpcx_workspace_bytes(B, N)
+    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    assert d_ws.data_ptr() % 256 == 0
+
+    bs = _lib.MpcxBatch(B, N, d_pd.data_ptr(), d_no.data_ptr(), d_xg.data_ptr())
+    rs = _lib.MpcxResult(d_X.data_ptr(), d_U.data_ptr(), d_st.data_ptr(), d_si.data_ptr(),
+                         d_qi.data_ptr(), d_co.data_ptr(), d_re.data_ptr())
+    stream = torch.cuda.current_stream()
+
+    def step():
+        rc = lib.mpcx_solve_batch_device(C.byref(bs), C.byref(opts), C.byref(rs),
+                                         d_ws.data_ptr(), ws_bytes, stream.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(lib.mpcx_last_error().decode())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in ev:
+        e0.record(stream)
+        step()
+        e1.record(stream)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if ev else 0.0
+
+    status = d_st.cpu().numpy()
+    sqp_it = d_si.cpu().numpy()
+    qp_it = d_qi.cpu().numpy()
+    n_conv = int((status == 0).sum())
+    fl = flops.algorithmic_flops(status, sqp_it, qp_it, N)
+
+    tot = torch.tensor([elapsed, float(n_conv), fl, float(B)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot[:1].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot[1:].clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        n_conv_all, fl_all, B_all = (float(v) for v in sm)
+    else:
+        n_conv_all, fl_all, B_all = float(n_conv), fl, float(B)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    steps = max(args.steps, 1)
+    value = n_conv_all * steps / elapsed
+    achieved_tf = fl / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    io_bytes = flops.algorithmic_io_bytes(N) * B
+    line = {
+        "metric": "converged OCPs/sec (N=50 kinematic car)",
+        "value": value, "unit": "OCP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "1M random start/goal pose OCPs, N=50, no obstacles, seed 20250310+rank",
+                   "problems_per_gpu": B, "N": N, "problems_total": int(B_all),
+                   "converged_fraction": n_conv_all / B_all,
+                   "solved_per_sec_all_statuses": B_all * steps / elapsed,
+                   "parallelism": f"independent batch slice per GPU x{world}"},
+        "roofline": {"bound": "valu_fp64", "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS,
+                     "traffic": None,
+                     "kernel": "mpcx_sqp_kernel<0>", "kernel_ms": kernel_ms,
+                     "algorithmic_flops_per_launch": fl,
+                     "batch_io_GBs": io_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0},
+    }
+
+    if args.cpu_sample > 0 and world == 1:
+        import oracle_lib
+        n = min(args.cpu_sample, B)
+        cores = min(16, os.cpu_count() or 1)
+        sample = packed.slice(0, n)
+        t1 = time.perf_counter()
+        ref = oracle_lib.solve_packed(sample, nthreads=cores)
+        dt = time.perf_counter() - t1
+        X = d_X[:n].cpu().numpy()
+        U = d_U[:n].cpu().numpy()
+        same = (np.array_equal(status[:n], ref["status"]) and np.array_equal(sqp_it[:n], ref["sqp_iter"])
+                and np.array_equal(qp_it[:n], ref["qp_iter"]))
+        okm = ref["status"] != 1
+        same = same and np.array_equal(X[okm], ref["X"][okm]) and np.array_equal(U[okm], ref["U"][okm])
+        line["cpu_baseline"] = {
+            "value": float((ref["status"] == 0).sum()) / dt, "unit": "OCP/s", "cores": cores,
+            "kind": "port",
+            "sample": f"first {n} problems of the same batch, CPU restatement (oracle), OpenMP {cores} threads, "
+                      f"{dt:.1f} s; all-status rate {n / dt:.0f}/s",
+            "gpu_matches_cpu_on_sample": bool(same)}
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,23 +1,36 @@
 // mpcx_kernels.hip — batched kinematic-car OCP solve on gfx950 (MI355X).
 //
-// One LANE per problem, 64 problems per wavefront, the whole SQP solve fused in
-// one persistent kernel.  The per-stage 7x7 algebra of the Riccati recursion is
-// a serial dependency chain over the N stages; giving each lane its own chain
-// keeps all 64 lanes of every FP64 instruction busy, which a wavefront that
-// cooperates on one 7x7 stage cannot.  Each lane's working set (iterate,
-// linearisation, multipliers, Riccati factors of all N+1 stages) lives in a
-// workspace in HBM laid out [wave][stage][field][lane], so every load and store
-// of a wavefront is one contiguous 512-byte segment.
+// Mapping.  One LANE per problem, 64 problems per wavefront, the whole SQP
+// solve fused in one persistent kernel.  The Riccati recursion is a serial
+// dependency chain over the N stages of ONE problem; a wavefront cooperating
+// on one 7x7 stage leaves most lanes idle and pays cross-lane latency on
+// every step, whereas 64 independent chains keep every FP64 instruction full.
+// The price is that a lane's working set (iterate, linearisation,
+// multipliers and Riccati factors of all N+1 stages, ~1.2 KB per stage) cannot
+// live on chip: it sits in an HBM workspace laid out [wave][stage][field][lane],
+// so each wavefront load/store is one contiguous 512-byte segment, and the
+// solver is organised as a few fused forward/backward SWEEPS over the stages
+// that touch each field as rarely as possible:
 //
-// The problem solved is the one reference src/core_solver.py:127-351 poses and
-// hands to acados at :354/:502; the algorithm is the one selected by its
-// options block :242-253 (SQP, ERK4 + forward sensitivities, Gauss-Newton +
-// Levenberg-Marquardt, interior-point QP with stage-wise Riccati recursion).
+//   L   forward : apply the SQP step, RK4 + sensitivities, NLP residuals,
+//                 cold start of the interior point (one per SQP iteration)
+//   B0  backward: apply the previous interior-point step, residuals, barrier
+//                 Hessian, Riccati factorisation + backward substitution
+//   F0  forward : affine step, its longest feasible length, centring sums
+//   B1  backward: corrector right-hand side + backward substitution
+//   F1  forward : corrector step and its length
+//   B2/F2       : centring-only re-solve when the corrector shortens the step
+//
+// The problem is the one reference src/core_solver.py:127-351 poses and hands
+// to acados at :354/:502; the algorithm is the one its options block :242-253
+// selects (SQP, ERK4 + forward sensitivities, Gauss-Newton + Levenberg-
+// Marquardt, interior-point QP by stage-wise Riccati recursion).
 //
 // Arithmetic contract: built with -ffp-contract=off; every fused multiply-add
 // is an explicit fma(); sin/cos are the polynomials below, not the device
-// library's.  The order of operations is fixed, so a CPU program that performs
-// the same sequence gets the same bits.
+// library's.  Structural zeros and ones of the sensitivity matrices are
+// skipped, which leaves every remaining operation and its order unchanged, so
+// a CPU program that performs the dense sequence gets the same bits.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,58 +47,61 @@
 namespace {
 
 // ---------------------------------------------------------------------------
-// workspace field map (doubles per stage), R = rows per stage = 9 + NH
+// workspace field map (doubles per stage and lane), R = rows per stage
 // ---------------------------------------------------------------------------
 template <int NH>
 struct Map {
     static constexpr int R = 9 + NH;
-    static constexpr int G = 2 + NH;           // general rows
     static constexpr int X = 0;                // 5  NLP state
     static constexpr int U = X + 5;            // 2  NLP input
-    static constexpr int PI = U + 2;           // 5  NLP dynamics multiplier
-    static constexpr int NLL = PI + 5;         // R  NLP multipliers, lower sides
-    static constexpr int NLU = NLL + R;        // R
-    static constexpr int A = NLU + R;          // 25 row-major
-    static constexpr int B = A + 25;           // 10 row-major
-    static constexpr int BV = B + 10;          // 5  dynamics gap
-    static constexpr int C = BV + 5;           // R  row values
-    static constexpr int JX = C + R;           // G  general-row Jacobians
-    static constexpr int JY = JX + G;          // G
-    static constexpr int V = JY + G;           // 7  QP primal [u; x]
-    static constexpr int QPI = V + 7;          // 5
-    static constexpr int LAML = QPI + 5;       // R
-    static constexpr int LAMU = LAML + R;
-    static constexpr int TL = LAMU + R;
-    static constexpr int TU = TL + R;
-    static constexpr int RG = TU + R;          // 7
-    static constexpr int RB = RG + 7;          // 5
-    static constexpr int RDL = RB + 5;         // R
-    static constexpr int RDU = RDL + R;
-    static constexpr int HT = RDU + R;         // 10: diag(7), hxx, hxy, hyy
-    static constexpr int GT = HT + 10;         // 7
-    static constexpr int K = GT + 7;           // 10 row-major [2][5]
-    static constexpr int KV = K + 10;          // 2
-    static constexpr int LDL = KV + 2;         // 3: l10, d0, d1
-    static constexpr int P = LDL + 3;          // 25 full symmetric
-    static constexpr int PV = P + 25;          // 5
-    static constexpr int DV = PV + 5;          // 7
+    static constexpr int AB = U + 2;           // 14 non-trivial sensitivities (see AbIdx)
+    static constexpr int BV = AB + 14;         // 5  dynamics gap
+    static constexpr int V = BV + 5;           // 7  QP primal [u; x]
+    static constexpr int QPI = V + 7;          // 5  QP dynamics multiplier
+    static constexpr int LAML = QPI + 5;       // R  multipliers, lower sides
+    static constexpr int LAMU = LAML + R;      // R
+    static constexpr int TL = LAMU + R;        // R  slacks
+    static constexpr int TU = TL + R;          // R
+    static constexpr int RG = TU + R;          // 7  stationarity residual
+    static constexpr int RB = RG + 7;          // 5  dynamics residual
+    static constexpr int PRB = RB + 5;         // 5  P(k+1) * rb
+    static constexpr int K = PRB + 5;          // 10 feedback gain, row-major [2][5]
+    static constexpr int LDL = K + 10;         // 3  l10, d0, d1 of M_uu
+    static constexpr int P = LDL + 3;          // 15 cost-to-go Hessian, lower triangle
+    static constexpr int KV = P + 15;          // 2  feed-forward
+    static constexpr int PV = KV + 2;          // 5  cost-to-go gradient
+    static constexpr int DV = PV + 5;          // 7  step
     static constexpr int DPI = DV + 7;         // 5
-    static constexpr int DVA = DPI + 5;        // 7
-    static constexpr int F = DVA + 7;          // doubles per stage
+    static constexpr int DVA = DPI + 5;        // 7  affine (predictor) step
+    static constexpr int F = DVA + 7;
+};
+
+// A = dPhi/dx and B = dPhi/du of one RK4 step have this pattern (h* = 6*(h/6)):
+//   A = [1 0 a02 a03 a04; 0 1 a12 a13 a14; 0 0 1 a23 a24; 0 0 0 1 0; 0 0 0 0 1]
+//   B = [b00 b01; b10 b11; b20 b21; h* 0; 0 h*]
+struct AB {
+    double a02, a03, a04, a12, a13, a14, a23, a24;
+    double b00, b10, b20, b01, b11, b21;
 };
 
 struct Lane {
-    double *w;            // workspace of this lane: element (k, f) at w[(k*F + f) * 64]
-    const double *pd;     // problem table column of this lane: field f at pd[f * B]
+    double *wave;         // workspace of this wavefront (same in all lanes); element (k, f)
+                          // of lane l is wave[(k*F + f) * 64 + l]
+    const double *pdata;  // problem table (same in all lanes); field f of problem b at [f*B + b]
     size_t B;
+    unsigned lane;        // 0..63
+    unsigned b;           // problem this lane is solving
     int N;
     int nobs;
     int F;
+    double h, hh, h6, hB, invL;
 };
 
-DEV double ldw(const Lane &L, int k, int f) { return L.w[((size_t)k * L.F + f) * 64]; }
-DEV void stw(const Lane &L, int k, int f, double v) { L.w[((size_t)k * L.F + f) * 64] = v; }
-DEV double ldp(const Lane &L, int f) { return L.pd[(size_t)f * L.B]; }
+// The wave-uniform part of every address stays in scalar registers; only the
+// lane (or problem) index is a vector offset.
+DEV double ldw(const Lane &L, int k, int f) { return (L.wave + ((size_t)k * L.F + f) * 64)[L.lane]; }
+DEV void stw(const Lane &L, int k, int f, double v) { (L.wave + ((size_t)k * L.F + f) * 64)[L.lane] = v; }
+DEV double ldp(const Lane &L, int f) { return (L.pdata + (size_t)f * L.B)[L.b]; }
 
 DEV double dabs(double a) { return (a < 0.0) ? -a : a; }
 DEV double dmax(double a, double b) { return (b > a) ? b : a; }
@@ -137,7 +153,8 @@ DEV void mx_sincos(double x, double &s, double &c)
 }
 
 // ---------------------------------------------------------------------------
-// model (reference core_solver.py:148-155) and its variational equation
+// model (reference core_solver.py:148-155) and one RK4 step with the
+// non-trivial part of its forward sensitivities
 // ---------------------------------------------------------------------------
 struct Jac { double j02, j03, j12, j13, j23, j24; };
 
@@ -161,186 +178,252 @@ DEV void model_eval(double invL, const double *x, const double *u, double *f, Ja
     J.j24 = (v * fma(tde, tde, 1.0)) * invL;
 }
 
-// Kout = J * S + dF/du; S, Kout are 5 x 7, columns (x0..x4, u0, u1)
-DEV void vde_eval(const Jac &J, const double (*S)[NZ], double (*Ko)[NZ])
+// rows 0..2 of K = J*S + dF/du for the columns (theta, v, delta, u0, u1).  Of
+// S only the heading row (s23 s24 s25 s26; its theta entry is 1) and the
+// entries s35 = dv/du0, s46 = ddelta/du1 enter.
+struct KS {
+    double k02, k12;                 // column theta (k22 = 0)
+    double k03, k13, k23;            // column v
+    double k04, k14, k24;            // column delta
+    double k05, k15, k25;            // column u0
+    double k06, k16, k26;            // column u1
+};
+
+DEV void vde_eval(const Jac &J, double s23, double s24, double s25, double s26,
+                  double s35, double s46, KS &K)
 {
-#pragma unroll
-    for (int c = 0; c < NZ; ++c) {
-        Ko[0][c] = fma(J.j03, S[3][c], J.j02 * S[2][c]);
-        Ko[1][c] = fma(J.j13, S[3][c], J.j12 * S[2][c]);
-        Ko[2][c] = fma(J.j24, S[4][c], J.j23 * S[3][c]);
-        Ko[3][c] = 0.0;
-        Ko[4][c] = 0.0;
-    }
-    Ko[3][NX + 0] = 1.0;
-    Ko[4][NX + 1] = 1.0;
+    K.k02 = J.j02;
+    K.k12 = J.j12;
+    K.k03 = fma(J.j03, 1.0, J.j02 * s23);
+    K.k13 = fma(J.j13, 1.0, J.j12 * s23);
+    K.k23 = J.j23;
+    K.k04 = J.j02 * s24;
+    K.k14 = J.j12 * s24;
+    K.k24 = J.j24;
+    K.k05 = fma(J.j03, s35, J.j02 * s25);
+    K.k15 = fma(J.j13, s35, J.j12 * s25);
+    K.k25 = J.j23 * s35;
+    K.k06 = J.j02 * s26;
+    K.k16 = J.j12 * s26;
+    K.k26 = J.j24 * s46;
 }
 
-DEV void rk4_sens(double h, double invL, const double *x, const double *u,
-                  double *xn, double (*A)[NX], double (*Bm)[NU])
+DEV void rk4_sens(const Lane &L, const double *x, const double *u, double *xn, AB &ab)
 {
-    const double hh = 0.5 * h, h6 = h / 6.0;
-    double k1[NX], k2[NX], k3[NX], k4[NX], xs[NX];
-    double S0[NX][NZ], Ss[NX][NZ], K1[NX][NZ], K2[NX][NZ], K3[NX][NZ], K4[NX][NZ];
+    const double h = L.h, hh = L.hh, h6 = L.h6;
+    double f[NX], xs[NX], xa[NX];
     Jac J;
+    KS K, A;
+    // stage 1 at S = [I | 0]
+    model_eval(L.invL, x, u, f, J);
+    vde_eval(J, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, K);
+    A = K;
 #pragma unroll
-    for (int i = 0; i < NX; ++i)
-#pragma unroll
-        for (int c = 0; c < NZ; ++c) S0[i][c] = (i == c) ? 1.0 : 0.0;
-
-    model_eval(invL, x, u, k1, J);
-    vde_eval(J, S0, K1);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        xs[i] = fma(hh, k1[i], x[i]);
-#pragma unroll
-        for (int c = 0; c < NZ; ++c) Ss[i][c] = fma(hh, K1[i][c], S0[i][c]);
+    for (int i = 0; i < NX; ++i) { xa[i] = f[i]; xs[i] = fma(hh, f[i], x[i]); }
+    // stage 2 at S = S0 + h/2 K1
+    model_eval(L.invL, xs, u, f, J);
+    {
+        KS Kn;
+        vde_eval(J, hh * K.k23, hh * K.k24, hh * K.k25, hh * K.k26, hh, hh, Kn);
+        K = Kn;
     }
-    model_eval(invL, xs, u, k2, J);
-    vde_eval(J, Ss, K2);
+#define ACC2(m) A.m = fma(2.0, K.m, A.m)
+    ACC2(k02); ACC2(k12); ACC2(k03); ACC2(k13); ACC2(k23); ACC2(k04); ACC2(k14); ACC2(k24);
+    ACC2(k05); ACC2(k15); ACC2(k25); ACC2(k06); ACC2(k16); ACC2(k26);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        xs[i] = fma(hh, k2[i], x[i]);
-#pragma unroll
-        for (int c = 0; c < NZ; ++c) Ss[i][c] = fma(hh, K2[i][c], S0[i][c]);
+    for (int i = 0; i < NX; ++i) { xa[i] = fma(2.0, f[i], xa[i]); xs[i] = fma(hh, f[i], x[i]); }
+    // stage 3 at S = S0 + h/2 K2
+    model_eval(L.invL, xs, u, f, J);
+    {
+        KS Kn;
+        vde_eval(J, hh * K.k23, hh * K.k24, hh * K.k25, hh * K.k26, hh, hh, Kn);
+        K = Kn;
     }
-    model_eval(invL, xs, u, k3, J);
-    vde_eval(J, Ss, K3);
+    ACC2(k02); ACC2(k12); ACC2(k03); ACC2(k13); ACC2(k23); ACC2(k04); ACC2(k14); ACC2(k24);
+    ACC2(k05); ACC2(k15); ACC2(k25); ACC2(k06); ACC2(k16); ACC2(k26);
+#undef ACC2
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        xs[i] = fma(h, k3[i], x[i]);
-#pragma unroll
-        for (int c = 0; c < NZ; ++c) Ss[i][c] = fma(h, K3[i][c], S0[i][c]);
+    for (int i = 0; i < NX; ++i) { xa[i] = fma(2.0, f[i], xa[i]); xs[i] = fma(h, f[i], x[i]); }
+    // stage 4 at S = S0 + h K3
+    model_eval(L.invL, xs, u, f, J);
+    {
+        KS Kn;
+        vde_eval(J, h * K.k23, h * K.k24, h * K.k25, h * K.k26, h, h, Kn);
+        K = Kn;
     }
-    model_eval(invL, xs, u, k4, J);
-    vde_eval(J, Ss, K4);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        double t = k1[i] + k4[i];
-        t = fma(2.0, k2[i], t);
-        t = fma(2.0, k3[i], t);
-        xn[i] = fma(h6, t, x[i]);
-#pragma unroll
-        for (int c = 0; c < NZ; ++c) {
-            double ts = K1[i][c] + K4[i][c];
-            ts = fma(2.0, K2[i][c], ts);
-            ts = fma(2.0, K3[i][c], ts);
-            double sv = fma(h6, ts, S0[i][c]);
-            if (c < NX) A[i][c] = sv; else Bm[i][c - NX] = sv;
-        }
-    }
+    for (int i = 0; i < NX; ++i) xn[i] = fma(h6, xa[i] + f[i], x[i]);
+    ab.a02 = h6 * (A.k02 + K.k02);
+    ab.a12 = h6 * (A.k12 + K.k12);
+    ab.a03 = h6 * (A.k03 + K.k03);
+    ab.a13 = h6 * (A.k13 + K.k13);
+    ab.a23 = h6 * (A.k23 + K.k23);
+    ab.a04 = h6 * (A.k04 + K.k04);
+    ab.a14 = h6 * (A.k14 + K.k14);
+    ab.a24 = h6 * (A.k24 + K.k24);
+    ab.b00 = h6 * (A.k05 + K.k05);
+    ab.b10 = h6 * (A.k15 + K.k15);
+    ab.b20 = h6 * (A.k25 + K.k25);
+    ab.b01 = h6 * (A.k06 + K.k06);
+    ab.b11 = h6 * (A.k16 + K.k16);
+    ab.b21 = h6 * (A.k26 + K.k26);
 }
 
-// ---------------------------------------------------------------------------
-// rows of a stage.  r: 0-1 input box, 2-6 state box, 7-8 corridor, 9.. obstacles
-// ---------------------------------------------------------------------------
-DEV void row_range(const Lane &L, int k, int &r0, int &r1)
-{
-    if (k == 0) { r0 = 0; r1 = NU; }
-    else if (k < L.N) { r0 = 0; r1 = 9 + L.nobs; }
-    else { r0 = NU; r1 = 9; }
-}
-
-DEV double row_lo(const Lane &L, int k, int r)
-{
-    if (r < NU) return ldp(L, MPCX_F_LBU + r);
-    if (r < ROW_G0) return (k == L.N) ? ldp(L, MPCX_F_LBXE + r - NU) : ldp(L, MPCX_F_LBX + r - NU);
-    if (r < 9) return ldp(L, MPCX_F_LG + r - ROW_G0);
-    return ldp(L, MPCX_F_LH);
-}
-
-DEV double row_up(const Lane &L, int k, int r)
-{
-    if (r < NU) return ldp(L, MPCX_F_UBU + r);
-    if (r < ROW_G0) return (k == L.N) ? ldp(L, MPCX_F_UBXE + r - NU) : ldp(L, MPCX_F_UBX + r - NU);
-    if (r < 9) return ldp(L, MPCX_F_UG + r - ROW_G0);
-    return ldp(L, MPCX_F_UH);
-}
-
-// J_r * v, v = [u; x]; jx, jy are the general row's Jacobian entries
 template <int NH>
-DEV double row_dot(const Lane &L, int k, int r, const double *v)
+DEV void load_ab(const Lane &L, int k, AB &ab)
 {
     typedef Map<NH> M;
+    ab.a02 = ldw(L, k, M::AB + 0);  ab.a03 = ldw(L, k, M::AB + 1);  ab.a04 = ldw(L, k, M::AB + 2);
+    ab.a12 = ldw(L, k, M::AB + 3);  ab.a13 = ldw(L, k, M::AB + 4);  ab.a14 = ldw(L, k, M::AB + 5);
+    ab.a23 = ldw(L, k, M::AB + 6);  ab.a24 = ldw(L, k, M::AB + 7);
+    ab.b00 = ldw(L, k, M::AB + 8);  ab.b10 = ldw(L, k, M::AB + 9);  ab.b20 = ldw(L, k, M::AB + 10);
+    ab.b01 = ldw(L, k, M::AB + 11); ab.b11 = ldw(L, k, M::AB + 12); ab.b21 = ldw(L, k, M::AB + 13);
+}
+
+template <int NH>
+DEV void store_ab(const Lane &L, int k, const AB &ab)
+{
+    typedef Map<NH> M;
+    stw(L, k, M::AB + 0, ab.a02);  stw(L, k, M::AB + 1, ab.a03);  stw(L, k, M::AB + 2, ab.a04);
+    stw(L, k, M::AB + 3, ab.a12);  stw(L, k, M::AB + 4, ab.a13);  stw(L, k, M::AB + 5, ab.a14);
+    stw(L, k, M::AB + 6, ab.a23);  stw(L, k, M::AB + 7, ab.a24);
+    stw(L, k, M::AB + 8, ab.b00);  stw(L, k, M::AB + 9, ab.b10);  stw(L, k, M::AB + 10, ab.b20);
+    stw(L, k, M::AB + 11, ab.b01); stw(L, k, M::AB + 12, ab.b11); stw(L, k, M::AB + 13, ab.b21);
+}
+
+// acc[c] += sum_i BA[i][c] * w[i], c = 0..6 ([B A] columns), i ascending
+DEV void add_BAt(const Lane &L, const AB &ab, const double *w, double *acc)
+{
+    // B column 0 = [b00 b10 b20 h* 0], column 1 = [b01 b11 b21 0 h*]
+    acc[0] = fma(L.hB, w[3], fma(ab.b20, w[2], fma(ab.b10, w[1], fma(ab.b00, w[0], acc[0]))));
+    acc[1] = fma(L.hB, w[4], fma(ab.b21, w[2], fma(ab.b11, w[1], fma(ab.b01, w[0], acc[1]))));
+    // A columns: e0, e1, [a02 a12 1 0 0], [a03 a13 a23 1 0], [a04 a14 a24 0 1]
+    acc[2] = acc[2] + w[0];
+    acc[3] = acc[3] + w[1];
+    acc[4] = fma(ab.a12, w[1], fma(ab.a02, w[0], acc[4])) + w[2];
+    acc[5] = fma(ab.a23, w[2], fma(ab.a13, w[1], fma(ab.a03, w[0], acc[5]))) + w[3];
+    acc[6] = fma(ab.a24, w[2], fma(ab.a14, w[1], fma(ab.a04, w[0], acc[6]))) + w[4];
+}
+
+// out[i] = acc0[i] + A[i][:] * dx + B[i][:] * du  (row-wise chains, j then c ascending)
+DEV void mul_AB(const Lane &L, const AB &ab, const double *dx, const double *du, const double *acc0,
+                double *out)
+{
+    out[0] = fma(ab.b01, du[1], fma(ab.b00, du[0],
+             fma(ab.a04, dx[4], fma(ab.a03, dx[3], fma(ab.a02, dx[2], acc0[0] + dx[0])))));
+    out[1] = fma(ab.b11, du[1], fma(ab.b10, du[0],
+             fma(ab.a14, dx[4], fma(ab.a13, dx[3], fma(ab.a12, dx[2], acc0[1] + dx[1])))));
+    out[2] = fma(ab.b21, du[1], fma(ab.b20, du[0],
+             fma(ab.a24, dx[4], fma(ab.a23, dx[3], acc0[2] + dx[2]))));
+    out[3] = fma(L.hB, du[0], acc0[3] + dx[3]);
+    out[4] = fma(L.hB, du[1], acc0[4] + dx[4]);
+}
+
+// ---------------------------------------------------------------------------
+// rows of a stage.  r: 0-1 input box, 2-6 state box, 7-8 corridor, 9.. obstacles.
+// Stage 0 has the input rows only, stage N the state and corridor rows only,
+// the stages between have all of them (obstacle row j only if j < nobs).
+// The per-stage code is instantiated once per KIND so that the set of rows is
+// known at compile time and a stage is ONE basic block: all its loads can be
+// issued before the first one is needed.
+// ---------------------------------------------------------------------------
+enum { FIRST = 0, MID = 1, LAST = 2 };
+
+template <int KIND> DEV constexpr bool row_present(int r)
+{
+    return (r < NU) ? (KIND != LAST) : (r < 9) ? (KIND != FIRST) : (KIND == MID);
+}
+template <int KIND> DEV constexpr bool var_present(int j)   // is v[j] a variable of this stage
+{
+    return (j < NU) ? (KIND != LAST) : (KIND != FIRST);
+}
+
+// problem constants of one lane that the row code of stages < N needs; loaded
+// once per sweep (the terminal stage reads its own few directly)
+template <int NH>
+struct PC {
+    double lbu[NU], ubu[NU], lbx[NX], ubx[NX], cg[4], lg[2], ug[2], lh, uh;
+    double goal[NX], w[NZ], hw[NZ], lmk;
+    double obs[3 * (NH > 0 ? NH : 1)];
+};
+
+template <int NH>
+DEV void load_pc(const Lane &L, const mpcx_opts &o, PC<NH> &pc)
+{
+#pragma unroll
+    for (int c = 0; c < NU; ++c) { pc.lbu[c] = ldp(L, MPCX_F_LBU + c); pc.ubu[c] = ldp(L, MPCX_F_UBU + c); }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        pc.lbx[i] = ldp(L, MPCX_F_LBX + i);
+        pc.ubx[i] = ldp(L, MPCX_F_UBX + i);
+        pc.goal[i] = ldp(L, MPCX_F_GOAL + i);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pc.cg[i] = ldp(L, MPCX_F_CG + i);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { pc.lg[i] = ldp(L, MPCX_F_LG + i); pc.ug[i] = ldp(L, MPCX_F_UG + i); }
+    pc.lh = ldp(L, MPCX_F_LH);
+    pc.uh = ldp(L, MPCX_F_UH);
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) { pc.w[j] = ldp(L, MPCX_F_W + j); pc.hw[j] = L.h * pc.w[j]; }
+    pc.lmk = o.lm_scale_by_h ? L.h * o.lm : o.lm;
+#pragma unroll
+    for (int i = 0; i < 3 * NH; ++i) pc.obs[i] = ldp(L, MPCX_F_OBS + i);
+}
+
+// bounds of row r (terminal state box for KIND == LAST)
+template <int NH, int KIND>
+DEV void row_bounds(const Lane &L, const PC<NH> &pc, int r, double &lo, double &up)
+{
+    if (r < NU) { lo = pc.lbu[r]; up = pc.ubu[r]; }
+    else if (r < ROW_G0) {
+        if (KIND == LAST) { lo = ldp(L, MPCX_F_LBXE + r - NU); up = ldp(L, MPCX_F_UBXE + r - NU); }
+        else { lo = pc.lbx[r - NU]; up = pc.ubx[r - NU]; }
+    }
+    else if (r < 9) { lo = pc.lg[r - ROW_G0]; up = pc.ug[r - ROW_G0]; }
+    else { lo = pc.lh; up = pc.uh; }
+}
+
+// value c of row r at (x, u) and, for general rows, its Jacobian (jx, jy) w.r.t. (x, y)
+template <int NH>
+DEV void row_geom(const PC<NH> &pc, int r, const double *x, const double *u,
+                  double &c, double &jx, double &jy)
+{
+    jx = 0.0;
+    jy = 0.0;
+    if (r < NU) c = u[r];
+    else if (r < ROW_G0) c = x[r - NU];
+    else if (r < 9) {
+        jx = pc.cg[2 * (r - ROW_G0)];
+        jy = pc.cg[2 * (r - ROW_G0) + 1];
+        c = fma(jy, x[1], jx * x[0]);
+    } else {
+        const int j = (r - 9 < NH) ? r - 9 : 0;
+        double dx = x[0] - pc.obs[3 * j], dy = x[1] - pc.obs[3 * j + 1];
+        c = fma(dy, dy, dx * dx) - pc.obs[3 * j + 2];
+        jx = 2.0 * dx;
+        jy = 2.0 * dy;
+    }
+}
+
+// J_r * v for v = [u; x]
+DEV double jdot(int r, double jx, double jy, const double *v)
+{
     if (r < ROW_G0) return v[r];
-    double jx = ldw(L, k, M::JX + r - ROW_G0), jy = ldw(L, k, M::JY + r - ROW_G0);
     return fma(jy, v[3], jx * v[2]);
 }
 
-// ---------------------------------------------------------------------------
-// linearisation of one SQP iteration
-// ---------------------------------------------------------------------------
-template <int NH>
-DEV void linearize(const Lane &L, const mpcx_opts &o)
+// cost gradient g and Gauss-Newton + LM diagonal Hd of a stage at (x, u)
+template <int NH, int KIND>
+DEV void cost_terms(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, const double *x,
+                    const double *u, double *g, double *Hd)
 {
-    typedef Map<NH> M;
-    const int N = L.N;
-    const double h = ldp(L, MPCX_F_H);
-    const double invL = 1.0 / ldp(L, MPCX_F_L);
-    double xk[NX], xn1[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xk[i] = ldw(L, 0, M::X + i);
-    for (int k = 0; k <= N; ++k) {
-        double uk[NU] = {0.0, 0.0};
-        if (k < N) {
-#pragma unroll
-            for (int c = 0; c < NU; ++c) uk[c] = ldw(L, k, M::U + c);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) xn1[i] = ldw(L, k + 1, M::X + i);
-            double xn[NX], A[NX][NX], Bm[NX][NU];
-            rk4_sens(h, invL, xk, uk, xn, A, Bm);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                stw(L, k, M::BV + i, xn[i] - xn1[i]);
-#pragma unroll
-                for (int j = 0; j < NX; ++j) stw(L, k, M::A + i * NX + j, A[i][j]);
-#pragma unroll
-                for (int c = 0; c < NU; ++c) stw(L, k, M::B + i * NU + c, Bm[i][c]);
-            }
-        }
-        int r0, r1;
-        row_range(L, k, r0, r1);
-#pragma unroll
-        for (int r = 0; r < M::R; ++r) {
-            if (r < r0 || r >= r1) continue;
-            double c;
-            if (r < NU) c = uk[r];
-            else if (r < ROW_G0) c = xk[r - NU];
-            else if (r < 9) {
-                double jx = ldp(L, MPCX_F_CG + 2 * (r - ROW_G0));
-                double jy = ldp(L, MPCX_F_CG + 2 * (r - ROW_G0) + 1);
-                stw(L, k, M::JX + r - ROW_G0, jx);
-                stw(L, k, M::JY + r - ROW_G0, jy);
-                c = fma(jy, xk[1], jx * xk[0]);
-            } else {
-                double ox = ldp(L, MPCX_F_OBS + 3 * (r - 9));
-                double oy = ldp(L, MPCX_F_OBS + 3 * (r - 9) + 1);
-                double rr = ldp(L, MPCX_F_OBS + 3 * (r - 9) + 2);
-                double dx = xk[0] - ox, dy = xk[1] - oy;
-                c = fma(dy, dy, dx * dx) - rr;
-                stw(L, k, M::JX + r - ROW_G0, 2.0 * dx);
-                stw(L, k, M::JY + r - ROW_G0, 2.0 * dy);
-            }
-            stw(L, k, M::C + r, c);
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) xk[i] = xn1[i];
-    }
-}
-
-// cost gradient g and Gauss-Newton + LM diagonal Hd of stage k at (x, u)
-DEV void cost_terms(const Lane &L, const mpcx_opts &o, int k, const double *x, const double *u,
-                    double *g, double *Hd)
-{
-    if (k < L.N) {
-        const double h = ldp(L, MPCX_F_H);
-        const double lmk = o.lm_scale_by_h ? h * o.lm : o.lm;
+    if (KIND != LAST) {
 #pragma unroll
         for (int j = 0; j < NZ; ++j) {
-            double hw = h * ldp(L, MPCX_F_W + j);
-            double z = (j < NU) ? u[j] : (x[j - NU] - ldp(L, MPCX_F_GOAL + j - NU));
-            Hd[j] = hw + lmk;
-            g[j] = hw * z;
+            double z = (j < NU) ? u[j] : (x[j - NU] - pc.goal[j - NU]);
+            Hd[j] = pc.hw[j] + pc.lmk;
+            g[j] = pc.hw[j] * z;
         }
     } else {
         Hd[0] = Hd[1] = 0.0;
@@ -349,782 +432,972 @@ DEV void cost_terms(const Lane &L, const mpcx_opts &o, int k, const double *x, c
         for (int i = 0; i < NX; ++i) {
             double we = ldp(L, MPCX_F_WE + i);
             Hd[NU + i] = we + o.lm;
-            g[NU + i] = we * (x[i] - ldp(L, MPCX_F_GOAL + i));
+            g[NU + i] = we * (x[i] - pc.goal[i]);
         }
     }
 }
 
-template <int NH>
+template <int NH, int KIND>
 DEV void load_xu(const Lane &L, int k, double *x, double *u)
 {
     typedef Map<NH> M;
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = ldw(L, k, M::X + i);
     u[0] = u[1] = 0.0;
-    if (k < L.N) {
+    if (KIND != LAST) {
         u[0] = ldw(L, k, M::U + 0);
         u[1] = ldw(L, k, M::U + 1);
     }
 }
 
-template <int NH>
-DEV void load_AB(const Lane &L, int k, double (*A)[NX], double (*Bm)[NU])
-{
-    typedef Map<NH> M;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-#pragma unroll
-        for (int j = 0; j < NX; ++j) A[i][j] = ldw(L, k, M::A + i * NX + j);
-#pragma unroll
-        for (int c = 0; c < NU; ++c) Bm[i][c] = ldw(L, k, M::B + i * NU + c);
-    }
-}
-
-// NLP residuals: stationarity, dynamics gap, inequality violation, complementarity
-template <int NH>
-DEV void nlp_residuals(const Lane &L, const mpcx_opts &o, double *res)
-{
-    typedef Map<NH> M;
-    const int N = L.N;
-    double rs = 0.0, re = 0.0, ri = 0.0, rc = 0.0;
-    for (int k = 0; k <= N; ++k) {
-        double x[NX], u[NU], g[NZ], Hd[NZ], gl[NZ];
-        load_xu<NH>(L, k, x, u);
-        cost_terms(L, o, k, x, u, g, Hd);
-#pragma unroll
-        for (int j = 0; j < NZ; ++j) gl[j] = g[j];
-        if (k < N) {
-            double A[NX][NX], Bm[NX][NU], pn[NX];
-            load_AB<NH>(L, k, A, Bm);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) pn[i] = ldw(L, k + 1, M::PI + i);
-#pragma unroll
-            for (int c = 0; c < NU; ++c)
-#pragma unroll
-                for (int i = 0; i < NX; ++i) gl[c] = fma(Bm[i][c], pn[i], gl[c]);
-#pragma unroll
-            for (int c = 0; c < NX; ++c)
-#pragma unroll
-                for (int i = 0; i < NX; ++i) gl[NU + c] = fma(A[i][c], pn[i], gl[NU + c]);
-        }
-        if (k > 0) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) gl[NU + i] = gl[NU + i] - ldw(L, k, M::PI + i);
-        }
-        int r0, r1;
-        row_range(L, k, r0, r1);
-#pragma unroll
-        for (int r = 0; r < M::R; ++r) {
-            if (r < r0 || r >= r1) continue;
-            double ll = ldw(L, k, M::NLL + r), lu = ldw(L, k, M::NLU + r);
-            double dl = lu - ll;
-            if (r < ROW_G0) gl[r] = gl[r] + dl;
-            else {
-                gl[2] = fma(ldw(L, k, M::JX + r - ROW_G0), dl, gl[2]);
-                gl[3] = fma(ldw(L, k, M::JY + r - ROW_G0), dl, gl[3]);
-            }
-            double c = ldw(L, k, M::C + r);
-            double sl = c - row_lo(L, k, r), su = row_up(L, k, r) - c;
-            ri = dmax(ri, -sl);
-            ri = dmax(ri, -su);
-            rc = dmax(rc, dabs(ll * sl));
-            rc = dmax(rc, dabs(lu * su));
-        }
-#pragma unroll
-        for (int j = 0; j < NZ; ++j) {
-            bool in = (j < NU) ? (k < N) : (k > 0);
-            if (in) rs = dmax(rs, dabs(gl[j]));
-        }
-        if (k < N) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) re = dmax(re, dabs(ldw(L, k, M::BV + i)));
-        }
-        if (k == 0) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) ri = dmax(ri, dabs(ldp(L, MPCX_F_X0 + i) - x[i]));
-        }
-    }
-    res[0] = rs; res[1] = re; res[2] = ri; res[3] = rc;
-}
-
-// ---------------------------------------------------------------------------
-// interior-point QP
-// ---------------------------------------------------------------------------
-struct QpRes { double g, b, d, m, mu; };
-
-template <int NH>
-DEV void qp_residuals(const Lane &L, const mpcx_opts &o, int m_total, QpRes &R)
-{
-    typedef Map<NH> M;
-    const int N = L.N;
-    double ng = 0.0, nb = 0.0, nd = 0.0, nm = 0.0, sum = 0.0;
-    for (int k = 0; k <= N; ++k) {
-        double x[NX], u[NU], g[NZ], Hd[NZ], v[NZ], rg[NZ];
-        load_xu<NH>(L, k, x, u);
-        cost_terms(L, o, k, x, u, g, Hd);
-#pragma unroll
-        for (int j = 0; j < NZ; ++j) {
-            v[j] = ldw(L, k, M::V + j);
-            rg[j] = fma(Hd[j], v[j], g[j]);
-        }
-        double A[NX][NX], Bm[NX][NU];
-        if (k < N) {
-            double pn[NX];
-            load_AB<NH>(L, k, A, Bm);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) pn[i] = ldw(L, k + 1, M::QPI + i);
-#pragma unroll
-            for (int c = 0; c < NU; ++c)
-#pragma unroll
-                for (int i = 0; i < NX; ++i) rg[c] = fma(Bm[i][c], pn[i], rg[c]);
-#pragma unroll
-            for (int c = 0; c < NX; ++c)
-#pragma unroll
-                for (int i = 0; i < NX; ++i) rg[NU + c] = fma(A[i][c], pn[i], rg[NU + c]);
-        }
-        if (k > 0) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) rg[NU + i] = rg[NU + i] - ldw(L, k, M::QPI + i);
-        }
-        int r0, r1;
-        row_range(L, k, r0, r1);
-#pragma unroll
-        for (int r = 0; r < M::R; ++r) {
-            if (r < r0 || r >= r1) continue;
-            double jv = row_dot<NH>(L, k, r, v);
-            double ll = ldw(L, k, M::LAML + r), lu = ldw(L, k, M::LAMU + r);
-            double tl = ldw(L, k, M::TL + r), tu = ldw(L, k, M::TU + r);
-            double dl = lu - ll;
-            if (r < ROW_G0) rg[r] = rg[r] + dl;
-            else {
-                rg[2] = fma(ldw(L, k, M::JX + r - ROW_G0), dl, rg[2]);
-                rg[3] = fma(ldw(L, k, M::JY + r - ROW_G0), dl, rg[3]);
-            }
-            double c = ldw(L, k, M::C + r);
-            double rdl = ((row_lo(L, k, r) - c) - jv) + tl;
-            double rdu = (jv - (row_up(L, k, r) - c)) + tu;
-            stw(L, k, M::RDL + r, rdl);
-            stw(L, k, M::RDU + r, rdu);
-            nd = dmax(nd, dabs(rdl));
-            nd = dmax(nd, dabs(rdu));
-            double ml = ll * tl, mu_ = lu * tu;
-            nm = dmax(nm, dabs(ml));
-            nm = dmax(nm, dabs(mu_));
-            sum = sum + ml;
-            sum = sum + mu_;
-        }
-#pragma unroll
-        for (int j = 0; j < NZ; ++j) {
-            stw(L, k, M::RG + j, rg[j]);
-            bool in = (j < NU) ? (k < N) : (k > 0);
-            if (in) ng = dmax(ng, dabs(rg[j]));
-        }
-        if (k < N) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double acc = ldw(L, k, M::BV + i);
-#pragma unroll
-                for (int j = 0; j < NX; ++j) acc = fma(A[i][j], v[NU + j], acc);
-#pragma unroll
-                for (int c = 0; c < NU; ++c) acc = fma(Bm[i][c], v[c], acc);
-                double rb = acc - ldw(L, k + 1, M::V + NU + i);
-                stw(L, k, M::RB + i, rb);
-                nb = dmax(nb, dabs(rb));
-            }
-        }
-    }
-    R.g = ng; R.b = nb; R.d = nd; R.m = nm;
-    R.mu = sum / (double)m_total;
-}
-
-template <int NH>
-DEV void qp_init(const Lane &L, const mpcx_opts &o)
-{
-    typedef Map<NH> M;
-    const int N = L.N;
-    const double thr0 = o.thr0, mu0 = o.mu0;
-    for (int k = 0; k <= N; ++k) {
-        double v[NZ];
-#pragma unroll
-        for (int j = 0; j < NZ; ++j) v[j] = 0.0;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) stw(L, k, M::QPI + i, 0.0);
-        if (k == 0) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) v[NU + i] = ldp(L, MPCX_F_X0 + i) - ldw(L, 0, M::X + i);
-        }
-        int r0, r1;
-        row_range(L, k, r0, r1);
-#pragma unroll
-        for (int r = 0; r < M::R; ++r) {
-            if (r < r0 || r >= r1) continue;
-            double c = ldw(L, k, M::C + r);
-            double dl = row_lo(L, k, r) - c, du = row_up(L, k, r) - c;
-            double tl, tu;
-            if (r < ROW_G0) {
-                tl = v[r] - dl;
-                tu = du - v[r];
-                if (tl < thr0) {
-                    if (tu < thr0) {
-                        v[r] = 0.5 * (dl + du);
-                        tl = thr0;
-                        tu = thr0;
-                    } else {
-                        tl = thr0;
-                        v[r] = dl + thr0;
-                    }
-                } else if (tu < thr0) {
-                    tu = thr0;
-                    v[r] = du - thr0;
-                }
-            } else {
-                double jv = row_dot<NH>(L, k, r, v);
-                tl = jv - dl;
-                tu = du - jv;
-                if (tl < thr0) tl = thr0;
-                if (tu < thr0) tu = thr0;
-            }
-            stw(L, k, M::TL + r, tl);
-            stw(L, k, M::TU + r, tu);
-            stw(L, k, M::LAML + r, mu0 / tl);
-            stw(L, k, M::LAMU + r, mu0 / tu);
-        }
-#pragma unroll
-        for (int j = 0; j < NZ; ++j) stw(L, k, M::V + j, v[j]);
-    }
-}
-
-// complementarity target of one row side for the three kinds of step
+// complementarity targets of the two sides of a row for the three kinds of step
 //   mode 0 affine: lam*t;  mode 1 corrector: lam*t + dt_a*dlam_a - sigma*mu;
-//   mode 2 centering: lam*t - sigma*mu
+//   mode 2 centring: lam*t - sigma*mu            (jda = J_r * affine step)
+// All three are computed and the lane's `mode` selects, so lanes in different
+// modes share one instruction stream.
 DEV void row_rm(int mode, double sigma_mu, double jda, double ll, double lu, double tl, double tu,
                 double til, double tiu, double rdl, double rdu, double &rml, double &rmu)
 {
-    rml = ll * tl;
-    rmu = lu * tu;
-    if (mode == 1) {
-        double dtl = jda - rdl;
-        double dtu = -jda - rdu;
-        double dll = -(fma(ll, dtl, rml) * til);
-        double dlu = -(fma(lu, dtu, rmu) * tiu);
-        rml = fma(dtl, dll, rml) - sigma_mu;
-        rmu = fma(dtu, dlu, rmu) - sigma_mu;
-    } else if (mode == 2) {
-        rml = rml - sigma_mu;
-        rmu = rmu - sigma_mu;
-    }
+    const double ml = ll * tl, mu_ = lu * tu;
+    const double dtl = jda - rdl;
+    const double dtu = -jda - rdu;
+    const double dll = -(fma(ll, dtl, ml) * til);
+    const double dlu = -(fma(lu, dtu, mu_) * tiu);
+    const double rml1 = fma(dtl, dll, ml) - sigma_mu;
+    const double rmu1 = fma(dtu, dlu, mu_) - sigma_mu;
+    const double rml2 = ml - sigma_mu;
+    const double rmu2 = mu_ - sigma_mu;
+    rml = (mode == 1) ? rml1 : (mode == 2) ? rml2 : ml;
+    rmu = (mode == 1) ? rmu1 : (mode == 2) ? rmu2 : mu_;
 }
 
-template <int NH>
-DEV void qp_build_rhs(const Lane &L, const mpcx_opts &o, int mode, double sigma_mu)
+// ---------------------------------------------------------------------------
+// sweep L (forward): SQP step, linearisation, NLP residuals, cold start
+// ---------------------------------------------------------------------------
+struct LAcc { double rs, re, ri, rc, cost; };
+
+template <int NH, int KIND>
+DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, bool first,
+                 double *xk, double *pik, LAcc &a)
 {
     typedef Map<NH> M;
-    const int N = L.N;
-    for (int k = 0; k <= N; ++k) {
-        double Ht[NZ], hxx = 0.0, hxy = 0.0, hyy = 0.0, gt[NZ], dva[NZ];
-        if (mode == 0) {
-            double x[NX], u[NU], g[NZ];
-            load_xu<NH>(L, k, x, u);
-            cost_terms(L, o, k, x, u, g, Ht);
+    const double thr0 = o.thr0, mu0 = o.mu0;
+    // loads
+    double uk[NU] = {0.0, 0.0}, vu[NU] = {0.0, 0.0};
+    double xn1[NX], vxn1[NX], pin1[NX];
+    double ll[M::R], lu[M::R];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { xn1[i] = 0.0; vxn1[i] = 0.0; pin1[i] = 0.0; }
+    if (KIND != LAST) {
+#pragma unroll
+        for (int c = 0; c < NU; ++c) { uk[c] = ldw(L, k, M::U + c); vu[c] = ldw(L, k, M::V + c); }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            xn1[i] = ldw(L, k + 1, M::X + i);
+            vxn1[i] = ldw(L, k + 1, M::V + NU + i);
+            pin1[i] = ldw(L, k + 1, M::QPI + i);
         }
+    }
+#pragma unroll
+    for (int r = 0; r < M::R; ++r) {
+        ll[r] = 0.0; lu[r] = 0.0;
+        if (!row_present<KIND>(r)) continue;
+        ll[r] = ldw(L, k, M::LAML + r);
+        lu[r] = ldw(L, k, M::LAMU + r);
+    }
+    // SQP step (nothing to add before the first QP; v is uninitialised then)
+    AB ab = {};
+    if (KIND != LAST) {
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            uk[c] = first ? uk[c] : uk[c] + vu[c];
+            stw(L, k, M::U + c, uk[c]);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn1[i] = first ? xn1[i] : xn1[i] + vxn1[i];
+        double xn[NX];
+        rk4_sens(L, xk, uk, xn, ab);
+        store_ab<NH>(L, k, ab);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double bv = xn[i] - xn1[i];
+            stw(L, k, M::BV + i, bv);
+            a.re = dmax(a.re, dabs(bv));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) stw(L, k, M::X + i, xk[i]);
+    // stationarity of the Lagrangian
+    double g[NZ], Hd[NZ], gl[NZ];
+    cost_terms<NH, KIND>(L, o, pc, xk, uk, g, Hd);
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) gl[j] = g[j];
+    if (KIND != LAST) add_BAt(L, ab, pin1, gl);
+    if (KIND != FIRST) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) gl[NU + i] = gl[NU + i] - pik[i];
+    }
+    double vq[NZ];
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) vq[j] = 0.0;
+    if (KIND == FIRST) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double d0 = ldp(L, MPCX_F_X0 + i) - xk[i];
+            vq[NU + i] = d0;
+            a.ri = dmax(a.ri, dabs(d0));
+        }
+    }
+    // rows: the multipliers of the last QP enter the residuals, then the cold start replaces them
+#pragma unroll
+    for (int r = 0; r < M::R; ++r) {
+        if (!row_present<KIND>(r)) continue;
+        const bool pr = (r < 9) || (r - 9 < L.nobs);
+        double c, jx, jy, lo, up;
+        row_geom<NH>(pc, r, xk, uk, c, jx, jy);
+        row_bounds<NH, KIND>(L, pc, r, lo, up);
+        double dl = lu[r] - ll[r];
+        if (r < ROW_G0) gl[r] = gl[r] + dl;
+        else {
+            gl[2] = pr ? fma(jx, dl, gl[2]) : gl[2];
+            gl[3] = pr ? fma(jy, dl, gl[3]) : gl[3];
+        }
+        double sl = c - lo, su = up - c;
+        double ri = dmax(dmax(a.ri, -sl), -su);
+        double rc = dmax(dmax(a.rc, dabs(ll[r] * sl)), dabs(lu[r] * su));
+        a.ri = pr ? ri : a.ri;
+        a.rc = pr ? rc : a.rc;
+        // cold start of the interior point for this row
+        double dlo = lo - c, dup = up - c, tl, tu;
+        if (r < ROW_G0) {
+            tl = vq[r] - dlo;
+            tu = dup - vq[r];
+            const bool bl = tl < thr0, bu = tu < thr0;
+            vq[r] = bl ? (bu ? 0.5 * (dlo + dup) : dlo + thr0) : (bu ? dup - thr0 : vq[r]);
+            tu = bu ? thr0 : tu;
+            tl = bl ? thr0 : tl;
+        } else {
+            double jv = jdot(r, jx, jy, vq);
+            tl = jv - dlo;
+            tu = dup - jv;
+            tl = (tl < thr0) ? thr0 : tl;
+            tu = (tu < thr0) ? thr0 : tu;
+        }
+        stw(L, k, M::TL + r, tl);
+        stw(L, k, M::TU + r, tu);
+        stw(L, k, M::LAML + r, mu0 / tl);
+        stw(L, k, M::LAMU + r, mu0 / tu);
+    }
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) {
+        if (var_present<KIND>(j)) a.rs = dmax(a.rs, dabs(gl[j]));
+        stw(L, k, M::V + j, vq[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) stw(L, k, M::QPI + i, 0.0);
+    // objective
+    if (KIND != LAST) {
 #pragma unroll
         for (int j = 0; j < NZ; ++j) {
-            gt[j] = ldw(L, k, M::RG + j);
-            dva[j] = (mode == 1) ? ldw(L, k, M::DVA + j) : 0.0;
+            double z = (j < NU) ? uk[j] : (xk[j - NU] - pc.goal[j - NU]);
+            double hw = (0.5 * L.h) * pc.w[j];
+            a.cost = fma(hw * z, z, a.cost);
         }
-        int r0, r1;
-        row_range(L, k, r0, r1);
+    } else {
 #pragma unroll
-        for (int r = 0; r < M::R; ++r) {
-            if (r < r0 || r >= r1) continue;
-            double ll = ldw(L, k, M::LAML + r), lu = ldw(L, k, M::LAMU + r);
-            double tl = ldw(L, k, M::TL + r), tu = ldw(L, k, M::TU + r);
-            double rdl = ldw(L, k, M::RDL + r), rdu = ldw(L, k, M::RDU + r);
-            double til = 1.0 / tl, tiu = 1.0 / tu;
-            double jx = 0.0, jy = 0.0;
-            if (r >= ROW_G0) {
-                jx = ldw(L, k, M::JX + r - ROW_G0);
-                jy = ldw(L, k, M::JY + r - ROW_G0);
-            }
-            double jda = 0.0;
-            if (mode == 1) jda = (r < ROW_G0) ? dva[r] : fma(jy, dva[3], jx * dva[2]);
-            double rml, rmu;
-            row_rm(mode, sigma_mu, jda, ll, lu, tl, tu, til, tiu, rdl, rdu, rml, rmu);
-            double ql = fma(-ll, rdl, rml) * til;
-            double qu = fma(-lu, rdu, rmu) * tiu;
-            double q = ql - qu;
-            if (r < ROW_G0) gt[r] = gt[r] + q;
-            else {
-                gt[2] = fma(jx, q, gt[2]);
-                gt[3] = fma(jy, q, gt[3]);
-            }
-            if (mode == 0) {
-                double w = ll * til + lu * tiu;
-                if (r < ROW_G0) Ht[r] = Ht[r] + w;
-                else {
-                    double wx = w * jx, wy = w * jy;
-                    hxx = fma(wx, jx, hxx);
-                    hxy = fma(wy, jx, hxy);
-                    hyy = fma(wy, jy, hyy);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NZ; ++j) stw(L, k, M::GT + j, gt[j]);
-        if (mode == 0) {
-#pragma unroll
-            for (int j = 0; j < NZ; ++j) stw(L, k, M::HT + j, Ht[j]);
-            stw(L, k, M::HT + 7, hxx);
-            stw(L, k, M::HT + 8, hxy);
-            stw(L, k, M::HT + 9, hyy);
+        for (int i = 0; i < NX; ++i) {
+            double z = xk[i] - pc.goal[i];
+            a.cost = fma((0.5 * ldp(L, MPCX_F_WE + i)) * z, z, a.cost);
         }
     }
-}
-
-// entry (r, c), r >= c, of the barrier Hessian given its stored pieces
-DEV double ht_entry(const double *Ht, int r, int c)
-{
-    if (r == c) {
-        if (r == 2) return Ht[2] + Ht[7];
-        if (r == 3) return Ht[3] + Ht[9];
-        return Ht[r];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        xk[i] = xn1[i];
+        pik[i] = pin1[i];
     }
-    if (r == 3 && c == 2) return Ht[8];
-    return 0.0;
 }
 
 template <int NH>
-DEV void riccati_factor(const Lane &L)
+DEV void sweep_L(const Lane &L, const mpcx_opts &o, bool first, double *res, double &cost_out)
 {
     typedef Map<NH> M;
     const int N = L.N;
-    double Pn[NX][NX];
-    {
-        double Ht[10];
+    PC<NH> pc;
+    load_pc<NH>(L, o, pc);
+    LAcc a = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double xk[NX], pik[NX];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) Ht[j] = ldw(L, N, M::HT + j);
+    for (int i = 0; i < NX; ++i) {
+        double x0 = ldw(L, 0, M::X + i), v0 = ldw(L, 0, M::V + NU + i);
+        xk[i] = first ? x0 : x0 + v0;
+        pik[i] = 0.0;
+    }
+    stage_L<NH, FIRST>(L, o, pc, 0, first, xk, pik, a);
+    for (int k = 1; k < N; ++k) stage_L<NH, MID>(L, o, pc, k, first, xk, pik, a);
+    stage_L<NH, LAST>(L, o, pc, N, first, xk, pik, a);
+    res[0] = a.rs; res[1] = a.re; res[2] = a.ri; res[3] = a.rc;
+    cost_out = a.cost;
+}
+
+// ---------------------------------------------------------------------------
+// backward sweeps
+// ---------------------------------------------------------------------------
+struct QpRes { double g, b, d, m, mu; };
+
+struct Step {          // the interior-point step waiting to be applied
+    bool have;
+    int mode;
+    double sigma_mu, alpha;
+};
+
+// P(k+1) lower triangle, packed row-wise: index of (i, j), i >= j
+DEV constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+DEV double psym(const double *P, int i, int j) { return (i >= j) ? P[tri(i, j)] : P[tri(j, i)]; }
+
+struct B0Carry {
+    double Pn[15], pn[NX], vxn[NX], qpin[NX];
+    double ng, nb, nd, nm, sum;
+};
+
+// B0: apply the pending step, residuals of the new iterate, barrier Hessian and
+// affine right-hand side, Riccati factorisation and backward substitution
+template <int NH, int KIND>
+DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, const Step &sp, B0Carry &cy)
+{
+    typedef Map<NH> M;
+    // ---- loads ----
+    double x[NX], u[NU], v[NZ], vo[NZ], dv[NZ], dva[NZ], qpi[NX], dpi[NX];
+    double ll[M::R], lu[M::R], tl[M::R], tu[M::R];
+    load_xu<NH, KIND>(L, k, x, u);
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) {
+        vo[j] = ldw(L, k, M::V + j);
+        dv[j] = ldw(L, k, M::DV + j);
+        dva[j] = ldw(L, k, M::DVA + j);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        qpi[i] = (KIND != FIRST) ? ldw(L, k, M::QPI + i) : 0.0;
+        dpi[i] = (KIND != FIRST) ? ldw(L, k, M::DPI + i) : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < M::R; ++r) {
+        ll[r] = lu[r] = tl[r] = tu[r] = 1.0;
+        if (!row_present<KIND>(r)) continue;
+        ll[r] = ldw(L, k, M::LAML + r);
+        lu[r] = ldw(L, k, M::LAMU + r);
+        tl[r] = ldw(L, k, M::TL + r);
+        tu[r] = ldw(L, k, M::TU + r);
+    }
+    AB ab = {};
+    double bv[NX];
+    if (KIND != LAST) {
+        load_ab<NH>(L, k, ab);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) bv[i] = ldw(L, k, M::BV + i);
+    }
+    // ---- pending step on the primal and the dynamics multiplier ----
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) {
+        v[j] = vo[j];
+        if (var_present<KIND>(j)) {
+            v[j] = sp.have ? fma(sp.alpha, dv[j], vo[j]) : vo[j];
+            stw(L, k, M::V + j, v[j]);
+        }
+    }
+    if (KIND != FIRST) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            qpi[i] = sp.have ? fma(sp.alpha, dpi[i], qpi[i]) : qpi[i];
+            stw(L, k, M::QPI + i, qpi[i]);
+        }
+    }
+    double g[NZ], Ht[NZ], rg[NZ], hxx = 0.0, hxy = 0.0, hyy = 0.0;
+    cost_terms<NH, KIND>(L, o, pc, x, u, g, Ht);
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) rg[j] = fma(Ht[j], v[j], g[j]);
+    if (KIND != LAST) add_BAt(L, ab, cy.qpin, rg);
+    if (KIND != FIRST) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) rg[NU + i] = rg[NU + i] - qpi[i];
+    }
+    // ---- rows ----
+    double qrow[M::R], gjx[M::R], gjy[M::R];
+#pragma unroll
+    for (int r = 0; r < M::R; ++r) {
+        qrow[r] = 0.0; gjx[r] = 0.0; gjy[r] = 0.0;
+        if (!row_present<KIND>(r)) continue;
+        const bool pr = (r < 9) || (r - 9 < L.nobs);
+        double c, jx, jy, lo, up;
+        row_geom<NH>(pc, r, x, u, c, jx, jy);
+        row_bounds<NH, KIND>(L, pc, r, lo, up);
+        const double dlo = lo - c, dup = up - c;
+        double l_l = ll[r], l_u = lu[r], t_l = tl[r], t_u = tu[r];
+        {
+            // pending step on this row's multipliers and slacks
+            double jvo = jdot(r, jx, jy, vo);
+            double rdl = (dlo - jvo) + t_l;
+            double rdu = (jvo - dup) + t_u;
+            double til = 1.0 / t_l, tiu = 1.0 / t_u;
+            double jda = jdot(r, jx, jy, dva);
+            double rml, rmu;
+            row_rm(sp.mode, sp.sigma_mu, jda, l_l, l_u, t_l, t_u, til, tiu, rdl, rdu, rml, rmu);
+            double jd = jdot(r, jx, jy, dv);
+            double dtl = jd - rdl;
+            double dtu = -jd - rdu;
+            double dll = -(fma(l_l, dtl, rml) * til);
+            double dlu = -(fma(l_u, dtu, rmu) * tiu);
+            double t;
+            t = fma(sp.alpha, dll, l_l); t = (t < o.lam_min) ? o.lam_min : t; l_l = sp.have ? t : l_l;
+            t = fma(sp.alpha, dlu, l_u); t = (t < o.lam_min) ? o.lam_min : t; l_u = sp.have ? t : l_u;
+            t = fma(sp.alpha, dtl, t_l); t = (t < o.t_min) ? o.t_min : t; t_l = sp.have ? t : t_l;
+            t = fma(sp.alpha, dtu, t_u); t = (t < o.t_min) ? o.t_min : t; t_u = sp.have ? t : t_u;
+            stw(L, k, M::LAML + r, l_l);
+            stw(L, k, M::LAMU + r, l_u);
+            stw(L, k, M::TL + r, t_l);
+            stw(L, k, M::TU + r, t_u);
+        }
+        double jv = jdot(r, jx, jy, v);
+        double dlm = l_u - l_l;
+        if (r < ROW_G0) rg[r] = rg[r] + dlm;
+        else {
+            rg[2] = pr ? fma(jx, dlm, rg[2]) : rg[2];
+            rg[3] = pr ? fma(jy, dlm, rg[3]) : rg[3];
+        }
+        double rdl = (dlo - jv) + t_l;
+        double rdu = (jv - dup) + t_u;
+        double nd = dmax(dmax(cy.nd, dabs(rdl)), dabs(rdu));
+        double ml = l_l * t_l, mu_ = l_u * t_u;
+        double nm = dmax(dmax(cy.nm, dabs(ml)), dabs(mu_));
+        double sum = (cy.sum + ml) + mu_;
+        cy.nd = pr ? nd : cy.nd;
+        cy.nm = pr ? nm : cy.nm;
+        cy.sum = pr ? sum : cy.sum;
+        // affine right-hand side and barrier Hessian
+        double til = 1.0 / t_l, tiu = 1.0 / t_u;
+        double ql = fma(-l_l, rdl, ml) * til;
+        double qu = fma(-l_u, rdu, mu_) * tiu;
+        qrow[r] = ql - qu;
+        gjx[r] = jx;
+        gjy[r] = jy;
+        double w = l_l * til + l_u * tiu;
+        if (r < ROW_G0) Ht[r] = Ht[r] + w;
+        else {
+            double wx = w * jx, wy = w * jy;
+            hxx = pr ? fma(wx, jx, hxx) : hxx;
+            hxy = pr ? fma(wy, jx, hxy) : hxy;
+            hyy = pr ? fma(wy, jy, hyy) : hyy;
+        }
+    }
+    double gt[NZ];
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) {
+        stw(L, k, M::RG + j, rg[j]);
+        if (var_present<KIND>(j)) cy.ng = dmax(cy.ng, dabs(rg[j]));
+        gt[j] = rg[j];
+    }
+#pragma unroll
+    for (int r = 0; r < M::R; ++r) {
+        if (!row_present<KIND>(r)) continue;
+        const bool pr = (r < 9) || (r - 9 < L.nobs);
+        if (r < ROW_G0) gt[r] = gt[r] + qrow[r];
+        else {
+            gt[2] = pr ? fma(gjx[r], qrow[r], gt[2]) : gt[2];
+            gt[3] = pr ? fma(gjy[r], qrow[r], gt[3]) : gt[3];
+        }
+    }
+    if (KIND == LAST) {
+        // P_N = barrier Hessian of the terminal state, p_N = its right-hand side
 #pragma unroll
         for (int i = 0; i < NX; ++i)
 #pragma unroll
             for (int j = 0; j <= i; ++j) {
-                double e = ht_entry(Ht, NU + i, NU + j);
-                Pn[i][j] = e;
-                Pn[j][i] = e;
+                double e = 0.0;
+                if (i == j) e = (i == 0) ? Ht[2] + hxx : (i == 1) ? Ht[3] + hyy : Ht[NU + i];
+                else if (i == 1 && j == 0) e = hxy;
+                cy.Pn[tri(i, j)] = e;
             }
 #pragma unroll
-        for (int i = 0; i < NX; ++i)
+        for (int i = 0; i < NX; ++i) cy.pn[i] = gt[NU + i];
+    } else {
+        // dynamics residual
+        double rb[NX];
+        mul_AB(L, ab, &v[NU], &v[0], bv, rb);
 #pragma unroll
-            for (int j = 0; j < NX; ++j) stw(L, N, M::P + i * NX + j, Pn[i][j]);
-    }
-    for (int k = N - 1; k >= 0; --k) {
-        double A[NX][NX], Bm[NX][NU], Ht[10];
-        load_AB<NH>(L, k, A, Bm);
+        for (int i = 0; i < NX; ++i) {
+            rb[i] = rb[i] - cy.vxn[i];
+            stw(L, k, M::RB + i, rb[i]);
+            cy.nb = dmax(cy.nb, dabs(rb[i]));
+        }
+        // w = p(k+1) + P(k+1) rb
+        double w[NX];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) Ht[j] = ldw(L, k, M::HT + j);
-        double PBA[NX][NZ], Mm[NZ][NZ];
+        for (int i = 0; i < NX; ++i) {
+            double acc = psym(cy.Pn, i, 0) * rb[0];
 #pragma unroll
-        for (int i = 0; i < NX; ++i)
+            for (int j = 1; j < NX; ++j) acc = fma(psym(cy.Pn, i, j), rb[j], acc);
+            stw(L, k, M::PRB + i, acc);
+            w[i] = cy.pn[i] + acc;
+        }
+        // PBA = P(k+1) [B A]; columns 0,1 = B, 2..6 = A
+        double PBA[NX][NZ];
 #pragma unroll
-            for (int c = 0; c < NZ; ++c) {
-                double acc = Pn[i][0] * ((c < NU) ? Bm[0][c] : A[0][c - NU]);
+        for (int i = 0; i < NX; ++i) {
+            const double p0 = psym(cy.Pn, i, 0), p1 = psym(cy.Pn, i, 1), p2 = psym(cy.Pn, i, 2),
+                         p3 = psym(cy.Pn, i, 3), p4 = psym(cy.Pn, i, 4);
+            PBA[i][0] = fma(p3, L.hB, fma(p2, ab.b20, fma(p1, ab.b10, p0 * ab.b00)));
+            PBA[i][1] = fma(p4, L.hB, fma(p2, ab.b21, fma(p1, ab.b11, p0 * ab.b01)));
+            PBA[i][2] = p0;
+            PBA[i][3] = p1;
+            PBA[i][4] = fma(p1, ab.a12, p0 * ab.a02) + p2;
+            PBA[i][5] = fma(p2, ab.a23, fma(p1, ab.a13, p0 * ab.a03)) + p3;
+            PBA[i][6] = fma(p2, ab.a24, fma(p1, ab.a14, p0 * ab.a04)) + p4;
+        }
+        // M = Ht + [B A]' PBA, lower triangle
+        double Mm[NZ][NZ];
 #pragma unroll
-                for (int j = 1; j < NX; ++j)
-                    acc = fma(Pn[i][j], (c < NU) ? Bm[j][c] : A[j][c - NU], acc);
-                PBA[i][c] = acc;
-            }
+        for (int c = 0; c < NZ; ++c) {
 #pragma unroll
-        for (int r = 0; r < NZ; ++r)
-#pragma unroll
-            for (int c = 0; c <= r; ++c) {
-                double acc = ht_entry(Ht, r, c);
-#pragma unroll
-                for (int i = 0; i < NX; ++i)
-                    acc = fma((r < NU) ? Bm[i][r] : A[i][r - NU], PBA[i][c], acc);
+            for (int r = c; r < NZ; ++r) {
+                double acc = 0.0;
+                if (r == c) acc = (r == 2) ? Ht[2] + hxx : (r == 3) ? Ht[3] + hyy : Ht[r];
+                else if (r == 3 && c == 2) acc = hxy;
+                if (r == 0)
+                    acc = fma(L.hB, PBA[3][c], fma(ab.b20, PBA[2][c], fma(ab.b10, PBA[1][c], fma(ab.b00, PBA[0][c], acc))));
+                else if (r == 1)
+                    acc = fma(L.hB, PBA[4][c], fma(ab.b21, PBA[2][c], fma(ab.b11, PBA[1][c], fma(ab.b01, PBA[0][c], acc))));
+                else if (r == 2) acc = acc + PBA[0][c];
+                else if (r == 3) acc = acc + PBA[1][c];
+                else if (r == 4) acc = fma(ab.a12, PBA[1][c], fma(ab.a02, PBA[0][c], acc)) + PBA[2][c];
+                else if (r == 5) acc = fma(ab.a23, PBA[2][c], fma(ab.a13, PBA[1][c], fma(ab.a03, PBA[0][c], acc))) + PBA[3][c];
+                else acc = fma(ab.a24, PBA[2][c], fma(ab.a14, PBA[1][c], fma(ab.a04, PBA[0][c], acc))) + PBA[4][c];
                 Mm[r][c] = acc;
             }
-        double d0 = Mm[0][0];
-        double l10 = Mm[1][0] / d0;
-        double d1 = fma(-l10, Mm[1][0], Mm[1][1]);
+        }
+        const double d0 = Mm[0][0];
+        const double l10 = Mm[1][0] / d0;
+        const double d1 = fma(-l10, Mm[1][0], Mm[1][1]);
         stw(L, k, M::LDL + 0, l10);
         stw(L, k, M::LDL + 1, d0);
         stw(L, k, M::LDL + 2, d1);
-        double K[NU][NX];
+        double Kg[NU][NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             double y0 = Mm[NU + i][0];
             double y1 = fma(-l10, y0, Mm[NU + i][1]);
             double z0 = y0 / d0, z1 = y1 / d1;
-            double s1 = z1;
-            double s0 = fma(-l10, s1, z0);
-            K[0][i] = -s0;
-            K[1][i] = -s1;
-            stw(L, k, M::K + i, K[0][i]);
-            stw(L, k, M::K + NX + i, K[1][i]);
+            double s0 = fma(-l10, z1, z0);
+            Kg[0][i] = -s0;
+            Kg[1][i] = -z1;
+            stw(L, k, M::K + i, Kg[0][i]);
+            stw(L, k, M::K + NX + i, Kg[1][i]);
         }
+        // right-hand side of this stage and feed-forward
+        double m[NZ];
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) m[j] = gt[j];
+        add_BAt(L, ab, w, m);
+        {
+            double y0 = m[0];
+            double y1 = fma(-l10, y0, m[1]);
+            double z0 = y0 / d0, z1 = y1 / d1;
+            double s0 = fma(-l10, z1, z0);
+            stw(L, k, M::KV + 0, -s0);
+            stw(L, k, M::KV + 1, -z1);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) cy.pn[i] = fma(Kg[1][i], m[1], fma(Kg[0][i], m[0], m[NU + i]));
+        // P(k) = M_xx + M_xu K
 #pragma unroll
         for (int i = 0; i < NX; ++i)
 #pragma unroll
             for (int j = 0; j <= i; ++j) {
-                double e = fma(Mm[NU + i][0], K[0][j], Mm[NU + i][NU + j]);
-                e = fma(Mm[NU + i][1], K[1][j], e);
-                Pn[i][j] = e;
-                Pn[j][i] = e;
+                double e = fma(Mm[NU + i][0], Kg[0][j], Mm[NU + i][NU + j]);
+                cy.Pn[tri(i, j)] = fma(Mm[NU + i][1], Kg[1][j], e);
             }
+    }
+    if (KIND != FIRST) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i)
+        for (int i = 0; i < 15; ++i) stw(L, k, M::P + i, cy.Pn[i]);
+    }
 #pragma unroll
-            for (int j = 0; j < NX; ++j) stw(L, k, M::P + i * NX + j, Pn[i][j]);
+    for (int i = 0; i < NX; ++i) {
+        cy.vxn[i] = v[NU + i];
+        cy.qpin[i] = qpi[i];
     }
 }
 
 template <int NH>
-DEV void riccati_solve(const Lane &L)
+DEV void sweep_B0(const Lane &L, const mpcx_opts &o, const Step &sp, int m_total, QpRes &R)
+{
+    const int N = L.N;
+    PC<NH> pc;
+    load_pc<NH>(L, o, pc);
+    B0Carry cy;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { cy.pn[i] = 0.0; cy.vxn[i] = 0.0; cy.qpin[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 15; ++i) cy.Pn[i] = 0.0;
+    cy.ng = cy.nb = cy.nd = cy.nm = cy.sum = 0.0;
+    stage_B0<NH, LAST>(L, o, pc, N, sp, cy);
+    for (int k = N - 1; k >= 1; --k) stage_B0<NH, MID>(L, o, pc, k, sp, cy);
+    stage_B0<NH, FIRST>(L, o, pc, 0, sp, cy);
+    R.g = cy.ng; R.b = cy.nb; R.d = cy.nd; R.m = cy.nm;
+    R.mu = cy.sum / (double)m_total;
+}
+
+// Bs: new right-hand side (mode 1 corrector, mode 2 centring), backward
+// substitution with the stored factors
+template <int NH, int KIND>
+DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int mode, double sigma_mu,
+                  double *pn)
 {
     typedef Map<NH> M;
-    const int N = L.N;
-    double pn[NX];
+    double x[NX], u[NU], v[NZ], dva[NZ], gt[NZ];
+    double ll[M::R], lu[M::R], tl[M::R], tu[M::R];
+    load_xu<NH, KIND>(L, k, x, u);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        pn[i] = ldw(L, N, M::GT + NU + i);
-        stw(L, N, M::PV + i, pn[i]);
+    for (int j = 0; j < NZ; ++j) {
+        v[j] = ldw(L, k, M::V + j);
+        dva[j] = ldw(L, k, M::DVA + j);
+        gt[j] = ldw(L, k, M::RG + j);
     }
-    for (int k = N - 1; k >= 0; --k) {
-        double A[NX][NX], Bm[NX][NU], Pn[NX][NX], rb[NX], gt[NZ], w[NX], m[NZ];
-        load_AB<NH>(L, k, A, Bm);
+#pragma unroll
+    for (int r = 0; r < M::R; ++r) {
+        ll[r] = lu[r] = tl[r] = tu[r] = 1.0;
+        if (!row_present<KIND>(r)) continue;
+        ll[r] = ldw(L, k, M::LAML + r);
+        lu[r] = ldw(L, k, M::LAMU + r);
+        tl[r] = ldw(L, k, M::TL + r);
+        tu[r] = ldw(L, k, M::TU + r);
+    }
+    AB ab = {};
+    double prb[NX], l10 = 0.0, d0 = 1.0, d1 = 1.0, k0[NX], k1[NX];
+    if (KIND != LAST) {
+        load_ab<NH>(L, k, ab);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            rb[i] = ldw(L, k, M::RB + i);
-#pragma unroll
-            for (int j = 0; j < NX; ++j) Pn[i][j] = ldw(L, k + 1, M::P + i * NX + j);
+            prb[i] = ldw(L, k, M::PRB + i);
+            k0[i] = ldw(L, k, M::K + i);
+            k1[i] = ldw(L, k, M::K + NX + i);
         }
+        l10 = ldw(L, k, M::LDL + 0);
+        d0 = ldw(L, k, M::LDL + 1);
+        d1 = ldw(L, k, M::LDL + 2);
+    }
 #pragma unroll
-        for (int j = 0; j < NZ; ++j) gt[j] = ldw(L, k, M::GT + j);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            double acc = pn[i];
-#pragma unroll
-            for (int j = 0; j < NX; ++j) acc = fma(Pn[i][j], rb[j], acc);
-            w[i] = acc;
+    for (int r = 0; r < M::R; ++r) {
+        if (!row_present<KIND>(r)) continue;
+        const bool pr = (r < 9) || (r - 9 < L.nobs);
+        double c, jx, jy, lo, up;
+        row_geom<NH>(pc, r, x, u, c, jx, jy);
+        row_bounds<NH, KIND>(L, pc, r, lo, up);
+        const double dlo = lo - c, dup = up - c;
+        double jv = jdot(r, jx, jy, v);
+        double rdl = (dlo - jv) + tl[r];
+        double rdu = (jv - dup) + tu[r];
+        double til = 1.0 / tl[r], tiu = 1.0 / tu[r];
+        double jda = jdot(r, jx, jy, dva);
+        double rml, rmu;
+        row_rm(mode, sigma_mu, jda, ll[r], lu[r], tl[r], tu[r], til, tiu, rdl, rdu, rml, rmu);
+        double ql = fma(-ll[r], rdl, rml) * til;
+        double qu = fma(-lu[r], rdu, rmu) * tiu;
+        double q = ql - qu;
+        if (r < ROW_G0) gt[r] = gt[r] + q;
+        else {
+            gt[2] = pr ? fma(jx, q, gt[2]) : gt[2];
+            gt[3] = pr ? fma(jy, q, gt[3]) : gt[3];
         }
+    }
+    if (KIND == LAST) {
 #pragma unroll
-        for (int c = 0; c < NZ; ++c) {
-            double acc = gt[c];
+        for (int i = 0; i < NX; ++i) pn[i] = gt[NU + i];
+    } else {
+        double w[NX], m[NZ];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) acc = fma((c < NU) ? Bm[i][c] : A[i][c - NU], w[i], acc);
-            m[c] = acc;
-        }
-        double l10 = ldw(L, k, M::LDL + 0), d0 = ldw(L, k, M::LDL + 1), d1 = ldw(L, k, M::LDL + 2);
+        for (int i = 0; i < NX; ++i) w[i] = pn[i] + prb[i];
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) m[j] = gt[j];
+        add_BAt(L, ab, w, m);
         double y0 = m[0];
         double y1 = fma(-l10, y0, m[1]);
         double z0 = y0 / d0, z1 = y1 / d1;
-        double s1 = z1;
-        double s0 = fma(-l10, s1, z0);
+        double s0 = fma(-l10, z1, z0);
         stw(L, k, M::KV + 0, -s0);
-        stw(L, k, M::KV + 1, -s1);
+        stw(L, k, M::KV + 1, -z1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) pn[i] = fma(k1[i], m[1], fma(k0[i], m[0], m[NU + i]));
+    }
+    if (KIND != FIRST) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) stw(L, k, M::PV + i, pn[i]);
+    }
+}
+
+template <int NH>
+DEV void sweep_Bs(const Lane &L, const mpcx_opts &o, int mode, double sigma_mu)
+{
+    const int N = L.N;
+    PC<NH> pc;
+    load_pc<NH>(L, o, pc);
+    double pn[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) pn[i] = 0.0;
+    stage_Bs<NH, LAST>(L, o, pc, N, mode, sigma_mu, pn);
+    for (int k = N - 1; k >= 1; --k) stage_Bs<NH, MID>(L, o, pc, k, mode, sigma_mu, pn);
+    stage_Bs<NH, FIRST>(L, o, pc, 0, mode, sigma_mu, pn);
+}
+
+// ---------------------------------------------------------------------------
+// forward sweeps.  AFFINE: stores the predictor step (DVA), returns its longest
+// feasible length and the centring sums.  Otherwise (mode 1 or 2 per lane):
+// stores the step (DV, DPI) and returns its longest feasible length.
+// ---------------------------------------------------------------------------
+struct FAcc { double alpha, s1, s2; };
+
+template <int NH, int KIND, bool AFFINE>
+DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int mode, double sigma_mu,
+                 double *dx, FAcc &a)
+{
+    typedef Map<NH> M;
+    double x[NX], u[NU], v[NZ], dva[NZ], dvk[NZ], dxn[NX];
+    double ll[M::R], lu[M::R], tl[M::R], tu[M::R];
+    load_xu<NH, KIND>(L, k, x, u);
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) {
+        v[j] = ldw(L, k, M::V + j);
+        dva[j] = AFFINE ? 0.0 : ldw(L, k, M::DVA + j);
+    }
+#pragma unroll
+    for (int r = 0; r < M::R; ++r) {
+        ll[r] = lu[r] = tl[r] = tu[r] = 1.0;
+        if (!row_present<KIND>(r)) continue;
+        ll[r] = ldw(L, k, M::LAML + r);
+        lu[r] = ldw(L, k, M::LAMU + r);
+        tl[r] = ldw(L, k, M::TL + r);
+        tu[r] = ldw(L, k, M::TU + r);
+    }
+    AB ab = {};
+    double rb[NX], kv[NU], kg[NU][NX], pv[NX], Pk[15];
+    if (KIND != LAST) {
+        load_ab<NH>(L, k, ab);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            double k0 = ldw(L, k, M::K + i), k1 = ldw(L, k, M::K + NX + i);
-            pn[i] = fma(k1, m[1], fma(k0, m[0], m[NU + i]));
-            stw(L, k, M::PV + i, pn[i]);
+            rb[i] = ldw(L, k, M::RB + i);
+            kg[0][i] = ldw(L, k, M::K + i);
+            kg[1][i] = ldw(L, k, M::K + NX + i);
+        }
+        kv[0] = ldw(L, k, M::KV + 0);
+        kv[1] = ldw(L, k, M::KV + 1);
+    }
+    if (!AFFINE && KIND != FIRST) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) pv[i] = ldw(L, k, M::PV + i);
+#pragma unroll
+        for (int i = 0; i < 15; ++i) Pk[i] = ldw(L, k, M::P + i);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { dvk[NU + i] = dx[i]; dxn[i] = 0.0; }
+    dvk[0] = dvk[1] = 0.0;
+    if (!AFFINE && KIND != FIRST) {
+        // multiplier step of the dynamics equation that defines x_k
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double acc = pv[i];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) acc = fma(psym(Pk, i, j), dx[j], acc);
+            stw(L, k, M::DPI + i, acc);
         }
     }
-    double dx[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        dx[i] = 0.0;
-        stw(L, 0, M::DV + NU + i, 0.0);
-    }
-    for (int k = 0; k < N; ++k) {
-        double A[NX][NX], Bm[NX][NU], du[NU], dxn[NX];
-        load_AB<NH>(L, k, A, Bm);
+    if (KIND != LAST) {
 #pragma unroll
         for (int c = 0; c < NU; ++c) {
-            double acc = ldw(L, k, M::KV + c);
+            double acc = kv[c];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) acc = fma(ldw(L, k, M::K + c * NX + i), dx[i], acc);
-            du[c] = acc;
-            stw(L, k, M::DV + c, acc);
+            for (int i = 0; i < NX; ++i) acc = fma(kg[c][i], dx[i], acc);
+            dvk[c] = acc;
         }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            double acc = ldw(L, k, M::RB + i);
-#pragma unroll
-            for (int j = 0; j < NX; ++j) acc = fma(A[i][j], dx[j], acc);
-#pragma unroll
-            for (int c = 0; c < NU; ++c) acc = fma(Bm[i][c], du[c], acc);
-            dxn[i] = acc;
-            stw(L, k + 1, M::DV + NU + i, acc);
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            double acc = ldw(L, k + 1, M::PV + i);
-#pragma unroll
-            for (int j = 0; j < NX; ++j) acc = fma(ldw(L, k + 1, M::P + i * NX + j), dxn[j], acc);
-            stw(L, k + 1, M::DPI + i, acc);
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) dx[i] = dxn[i];
+        mul_AB(L, ab, dx, dvk, rb, dxn);
     }
-    stw(L, N, M::DV + 0, 0.0);
-    stw(L, N, M::DV + 1, 0.0);
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) stw(L, k, (AFFINE ? M::DVA : M::DV) + j, dvk[j]);
+#pragma unroll
+    for (int r = 0; r < M::R; ++r) {
+        if (!row_present<KIND>(r)) continue;
+        const bool pr = (r < 9) || (r - 9 < L.nobs);
+        double c, jx, jy, lo, up;
+        row_geom<NH>(pc, r, x, u, c, jx, jy);
+        row_bounds<NH, KIND>(L, pc, r, lo, up);
+        const double dlo = lo - c, dup = up - c;
+        double jv = jdot(r, jx, jy, v);
+        double rdl = (dlo - jv) + tl[r];
+        double rdu = (jv - dup) + tu[r];
+        double til = 1.0 / tl[r], tiu = 1.0 / tu[r];
+        double jda = AFFINE ? 0.0 : jdot(r, jx, jy, dva);
+        double rml, rmu;
+        if (AFFINE) { rml = ll[r] * tl[r]; rmu = lu[r] * tu[r]; }
+        else row_rm(mode, sigma_mu, jda, ll[r], lu[r], tl[r], tu[r], til, tiu, rdl, rdu, rml, rmu);
+        double jd = jdot(r, jx, jy, dvk);
+        double dtl = jd - rdl;
+        double dtu = -jd - rdu;
+        double dll = -(fma(ll[r], dtl, rml) * til);
+        double dlu = -(fma(lu[r], dtu, rmu) * tiu);
+        double al = a.alpha;
+        { double cnd = -ll[r] / dll; al = (dll < 0.0 && cnd < al) ? cnd : al; }
+        { double cnd = -tl[r] / dtl; al = (dtl < 0.0 && cnd < al) ? cnd : al; }
+        { double cnd = -lu[r] / dlu; al = (dlu < 0.0 && cnd < al) ? cnd : al; }
+        { double cnd = -tu[r] / dtu; al = (dtu < 0.0 && cnd < al) ? cnd : al; }
+        a.alpha = pr ? al : a.alpha;
+        if (AFFINE) {
+            double s1 = a.s1, s2 = a.s2;
+            s1 = fma(ll[r], dtl, s1);
+            s1 = fma(tl[r], dll, s1);
+            s1 = fma(lu[r], dtu, s1);
+            s1 = fma(tu[r], dlu, s1);
+            s2 = fma(dtl, dll, s2);
+            s2 = fma(dtu, dlu, s2);
+            a.s1 = pr ? s1 : a.s1;
+            a.s2 = pr ? s2 : a.s2;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx[i] = dxn[i];
 }
 
-// one pass over all row sides: either the longest feasible step and the sums
-// S1, S2 (update == false) or the update itself with step alpha (update == true)
-template <int NH, bool UPDATE>
-DEV double qp_rows_pass(const Lane &L, const mpcx_opts &o, int mode, double sigma_mu,
-                        double alpha_in, double &S1, double &S2)
+template <int NH, bool AFFINE>
+DEV double sweep_F(const Lane &L, const mpcx_opts &o, int mode, double sigma_mu, double &S1, double &S2)
 {
-    typedef Map<NH> M;
     const int N = L.N;
-    double alpha = 1.0, s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k <= N; ++k) {
-        double dv[NZ], dva[NZ];
+    PC<NH> pc;
+    load_pc<NH>(L, o, pc);
+    FAcc a = {1.0, 0.0, 0.0};
+    double dx[NX];
 #pragma unroll
-        for (int j = 0; j < NZ; ++j) {
-            dv[j] = ldw(L, k, M::DV + j);
-            dva[j] = (mode == 1) ? ldw(L, k, M::DVA + j) : 0.0;
-        }
-        int r0, r1;
-        row_range(L, k, r0, r1);
-#pragma unroll
-        for (int r = 0; r < M::R; ++r) {
-            if (r < r0 || r >= r1) continue;
-            double ll = ldw(L, k, M::LAML + r), lu = ldw(L, k, M::LAMU + r);
-            double tl = ldw(L, k, M::TL + r), tu = ldw(L, k, M::TU + r);
-            double rdl = ldw(L, k, M::RDL + r), rdu = ldw(L, k, M::RDU + r);
-            double til = 1.0 / tl, tiu = 1.0 / tu;
-            double jx = 0.0, jy = 0.0;
-            if (r >= ROW_G0) {
-                jx = ldw(L, k, M::JX + r - ROW_G0);
-                jy = ldw(L, k, M::JY + r - ROW_G0);
-            }
-            double jda = 0.0;
-            if (mode == 1) jda = (r < ROW_G0) ? dva[r] : fma(jy, dva[3], jx * dva[2]);
-            double rml, rmu;
-            row_rm(mode, sigma_mu, jda, ll, lu, tl, tu, til, tiu, rdl, rdu, rml, rmu);
-            double jd = (r < ROW_G0) ? dv[r] : fma(jy, dv[3], jx * dv[2]);
-            double dtl = jd - rdl;
-            double dtu = -jd - rdu;
-            double dll = -(fma(ll, dtl, rml) * til);
-            double dlu = -(fma(lu, dtu, rmu) * tiu);
-            if (!UPDATE) {
-                if (dll < 0.0) { double c = -ll / dll; if (c < alpha) alpha = c; }
-                if (dtl < 0.0) { double c = -tl / dtl; if (c < alpha) alpha = c; }
-                if (dlu < 0.0) { double c = -lu / dlu; if (c < alpha) alpha = c; }
-                if (dtu < 0.0) { double c = -tu / dtu; if (c < alpha) alpha = c; }
-                s1 = fma(ll, dtl, s1);
-                s1 = fma(tl, dll, s1);
-                s1 = fma(lu, dtu, s1);
-                s1 = fma(tu, dlu, s1);
-                s2 = fma(dtl, dll, s2);
-                s2 = fma(dtu, dlu, s2);
-            } else {
-                double v;
-                v = fma(alpha_in, dll, ll); stw(L, k, M::LAML + r, (v < o.lam_min) ? o.lam_min : v);
-                v = fma(alpha_in, dlu, lu); stw(L, k, M::LAMU + r, (v < o.lam_min) ? o.lam_min : v);
-                v = fma(alpha_in, dtl, tl); stw(L, k, M::TL + r, (v < o.t_min) ? o.t_min : v);
-                v = fma(alpha_in, dtu, tu); stw(L, k, M::TU + r, (v < o.t_min) ? o.t_min : v);
-            }
-        }
-        if (UPDATE) {
-#pragma unroll
-            for (int j = 0; j < NZ; ++j) {
-                bool in = (j < NU) ? (k < N) : (k > 0);
-                if (in) stw(L, k, M::V + j, fma(alpha_in, dv[j], ldw(L, k, M::V + j)));
-            }
-            if (k > 0) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i)
-                    stw(L, k, M::QPI + i, fma(alpha_in, ldw(L, k, M::DPI + i), ldw(L, k, M::QPI + i)));
-            }
-        }
-    }
-    S1 = s1;
-    S2 = s2;
-    return alpha;
-}
-
-// HPIPM-style status: 0 solved, 1 iteration limit, 2 minimum step, 3 NaN
-template <int NH>
-DEV int qp_solve(const Lane &L, const mpcx_opts &o, int &iters)
-{
-    typedef Map<NH> M;
-    const int N = L.N;
-    // row sides: stage 0 has the 2 input rows, stages 1..N-1 all rows, stage N the 7 state rows
-    const int m_total = 2 * (NU + (N - 1) * (9 + L.nobs) + 7);
-    QpRes R;
-    qp_init<NH>(L, o);
-    qp_residuals<NH>(L, o, m_total, R);
-    int it = 0, status = 1;
-    for (;;) {
-        if (!(finite_d(R.g) && finite_d(R.b) && finite_d(R.d) && finite_d(R.m))) { status = 3; break; }
-        if (R.g < o.qp_tol_stat && R.b < o.qp_tol_eq && R.d < o.qp_tol_ineq && R.m < o.qp_tol_comp) { status = 0; break; }
-        if (it >= o.max_qp_iter) { status = 1; break; }
-        qp_build_rhs<NH>(L, o, 0, 0.0);
-        riccati_factor<NH>(L);
-        riccati_solve<NH>(L);
-        double S1, S2, d1, d2;
-        double a_aff = qp_rows_pass<NH, false>(L, o, 0, 0.0, 0.0, S1, S2);
-        double S0 = R.mu * (double)m_total;
-        double mu_aff = fma(a_aff, fma(a_aff, S2, S1), S0) / (double)m_total;
-        if (mu_aff < 0.0) mu_aff = 0.0;
-        double ratio = mu_aff / R.mu;
-        double sigma = ratio * ratio * ratio;
-        double sigma_mu = sigma * R.mu;
-        for (int k = 0; k <= N; ++k) {
-#pragma unroll
-            for (int j = 0; j < NZ; ++j) stw(L, k, M::DVA + j, ldw(L, k, M::DV + j));
-        }
-        int mode = 1;
-        qp_build_rhs<NH>(L, o, 1, sigma_mu);
-        riccati_solve<NH>(L);
-        double alpha = qp_rows_pass<NH, false>(L, o, 1, sigma_mu, 0.0, d1, d2);
-        if (o.cond_pred_corr && alpha < a_aff) {
-            mode = 2;
-            qp_build_rhs<NH>(L, o, 2, sigma_mu);
-            riccati_solve<NH>(L);
-            alpha = qp_rows_pass<NH, false>(L, o, 2, sigma_mu, 0.0, d1, d2);
-        }
-        if (!(alpha > o.alpha_min)) { status = finite_d(alpha) ? 2 : 3; ++it; break; }
-        alpha = alpha * fma(alpha, 0.9999999, (1.0 - alpha) * 0.99);
-        qp_rows_pass<NH, true>(L, o, mode, sigma_mu, alpha, d1, d2);
-        ++it;
-        qp_residuals<NH>(L, o, m_total, R);
-    }
-    iters = it;
-    return status;
-}
-
-template <int NH>
-DEV double nlp_cost(const Lane &L)
-{
-    typedef Map<NH> M;
-    const int N = L.N;
-    const double h = ldp(L, MPCX_F_H);
-    double c = 0.0;
-    for (int k = 0; k < N; ++k) {
-#pragma unroll
-        for (int j = 0; j < NZ; ++j) {
-            double z = (j < NU) ? ldw(L, k, M::U + j)
-                                : (ldw(L, k, M::X + j - NU) - ldp(L, MPCX_F_GOAL + j - NU));
-            double hw = (0.5 * h) * ldp(L, MPCX_F_W + j);
-            c = fma(hw * z, z, c);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        double z = ldw(L, N, M::X + i) - ldp(L, MPCX_F_GOAL + i);
-        c = fma((0.5 * ldp(L, MPCX_F_WE + i)) * z, z, c);
-    }
-    return c;
+    for (int i = 0; i < NX; ++i) dx[i] = 0.0;
+    stage_F<NH, FIRST, AFFINE>(L, o, pc, 0, mode, sigma_mu, dx, a);
+    for (int k = 1; k < N; ++k) stage_F<NH, MID, AFFINE>(L, o, pc, k, mode, sigma_mu, dx, a);
+    stage_F<NH, LAST, AFFINE>(L, o, pc, N, mode, sigma_mu, dx, a);
+    S1 = a.s1;
+    S2 = a.s2;
+    return a.alpha;
 }
 
 // ---------------------------------------------------------------------------
-// the fused solve: one lane = one problem, from initial guess to result
+// the fused solve.  Every lane runs a small state machine over its own problem;
+// the wavefront executes the sweeps in a fixed order each TICK and a lane joins
+// the sweeps its state calls for.  A lane whose problem ends takes the next
+// unsolved problem from a global counter, so lanes stay busy although problems
+// need very different numbers of iterations.  Which lane solves which problem
+// does not influence any result.
 // ---------------------------------------------------------------------------
+enum LaneState {
+    LS_FETCH = 0,   // needs a problem
+    LS_LIN = 1,     // needs sweep L (new SQP iteration)
+    LS_FACT = 2,    // interior point: needs B0 + F0 (new iteration)
+    LS_SOLVE = 3,   // interior point: needs Bs + F with `mode`
+    LS_DONE = 4     // no problems left
+};
+
 template <int NH>
 __global__ void __launch_bounds__(64)
-mpcx_sqp_kernel(mpcx_batch in, mpcx_opts o, mpcx_result out, double *workspace, int n_groups)
+mpcx_sqp_kernel(mpcx_batch in, mpcx_opts o, mpcx_result out, double *workspace, int *counter)
 {
     typedef Map<NH> M;
-    const int lane = threadIdx.x;
     const int N = in.N;
-    const size_t B = (size_t)in.B;
+    const unsigned B = (unsigned)in.B;
     const size_t wave_doubles = (size_t)(N + 1) * M::F * 64;
-    double *wbase = workspace + (size_t)blockIdx.x * wave_doubles + lane;
 
-    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        const size_t b = (size_t)grp * 64 + lane;
-        if (b >= B) continue;          // no barrier is used anywhere below
-        Lane L;
-        L.w = wbase;
-        L.pd = in.pdata + b;
-        L.B = B;
-        L.N = N;
-        L.F = M::F;
-        L.nobs = in.n_obs ? in.n_obs[b] : 0;
-        if (L.nobs < 0 || L.nobs > NH) {   // host validates; keep memory safe regardless
-            out.status[b] = MPCX_NAN;
-            continue;
-        }
-        // initial iterate: x from the guess, u = 0, all multipliers 0
-        for (int k = 0; k <= N; ++k) {
+    Lane L;
+    L.wave = workspace + (size_t)blockIdx.x * wave_doubles;
+    L.pdata = in.pdata;
+    L.B = (size_t)in.B;
+    L.lane = threadIdx.x;
+    L.b = 0;
+    L.N = N;
+    L.F = M::F;
+    L.nobs = 0;
+    L.h = L.hh = L.h6 = L.hB = L.invL = 0.0;
+
+    int state = LS_FETCH;
+    int status = MPCX_MAXITER, sqp_it = 0, qp_it = 0, qp_total = 0, mode = 1, m_total = 0;
+    bool first = true;
+    double res[4] = {0.0, 0.0, 0.0, 0.0};
+    double cost = 0.0, a_aff = 0.0, sigma_mu = 0.0;
+    QpRes R = {0.0, 0.0, 0.0, 0.0, 0.0};
+    Step sp;
+    sp.have = false; sp.mode = 0; sp.sigma_mu = 0.0; sp.alpha = 0.0;
+
+    for (;;) {
+        // ---- A: take a problem, write the initial iterate -------------------------------
+        if (state == LS_FETCH) {
+            unsigned b = (unsigned)atomicAdd(counter, 1);
+            if (b >= B) {
+                state = LS_DONE;
+            } else {
+                L.b = b;
+                int nobs = in.n_obs ? in.n_obs[b] : 0;
+                if (nobs < 0 || nobs > NH) {     // the host validates; stay memory safe regardless
+                    out.status[b] = MPCX_NAN;
+                    out.sqp_iter[b] = 0;
+                    out.qp_iter[b] = 0;
+                } else {
+                    L.nobs = nobs;
+                    L.h = ldp(L, MPCX_F_H);
+                    L.hh = 0.5 * L.h;
+                    L.h6 = L.h / 6.0;
+                    L.hB = L.h6 * 6.0;
+                    L.invL = 1.0 / ldp(L, MPCX_F_L);
+                    // row sides: stage 0 has the 2 input rows, stages 1..N-1 all rows, stage N 7 rows
+                    m_total = 2 * (NU + (N - 1) * (9 + nobs) + 7);
+                    for (int k = 0; k <= N; ++k) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                stw(L, k, M::X + i, in.xguess[((size_t)k * NX + i) * B + b]);
-                stw(L, k, M::PI + i, 0.0);
-            }
-            stw(L, k, M::U + 0, 0.0);
-            stw(L, k, M::U + 1, 0.0);
+                        for (int i = 0; i < NX; ++i) {
+                            stw(L, k, M::X + i, in.xguess[((size_t)k * NX + i) * L.B + b]);
+                            stw(L, k, M::QPI + i, 0.0);
+                        }
+                        stw(L, k, M::U + 0, 0.0);
+                        stw(L, k, M::U + 1, 0.0);
 #pragma unroll
-            for (int r = 0; r < M::R; ++r) {
-                stw(L, k, M::NLL + r, 0.0);
-                stw(L, k, M::NLU + r, 0.0);
+                        for (int r = 0; r < M::R; ++r) {
+                            stw(L, k, M::LAML + r, 0.0);
+                            stw(L, k, M::LAMU + r, 0.0);
+                        }
+                    }
+                    status = MPCX_MAXITER;
+                    sqp_it = 0;
+                    qp_total = 0;
+                    first = true;
+                    state = LS_LIN;
+                }
             }
         }
-        int status = MPCX_MAXITER, it = 0, qp_total = 0;
-        double res[4] = {0.0, 0.0, 0.0, 0.0};
-        for (;;) {
-            linearize<NH>(L, o);
-            nlp_residuals<NH>(L, o, res);
-            if (!(finite_d(res[0]) && finite_d(res[1]) && finite_d(res[2]) && finite_d(res[3]))) {
-                status = MPCX_NAN;
-                break;
-            }
-            if (!o.rti && res[0] < o.tol_stat && res[1] < o.tol_eq && res[2] < o.tol_ineq &&
-                res[3] < o.tol_comp) {
+        if (!__any(state != LS_DONE)) break;
+
+        // ---- B: SQP level -----------------------------------------------------------------
+        bool finished = false;
+        if (state == LS_LIN) {
+            if (o.rti && !first) {
+                // real-time iteration: apply the one step, report the new objective
+                double res_after[4];
+                sweep_L<NH>(L, o, false, res_after, cost);
                 status = MPCX_SUCCESS;
-                break;
+                finished = true;
+            } else {
+                sweep_L<NH>(L, o, first, res, cost);
+                first = false;
+                if (!(finite_d(res[0]) && finite_d(res[1]) && finite_d(res[2]) && finite_d(res[3]))) {
+                    status = MPCX_NAN;
+                    finished = true;
+                } else if (!o.rti && res[0] < o.tol_stat && res[1] < o.tol_eq && res[2] < o.tol_ineq &&
+                           res[3] < o.tol_comp) {
+                    status = MPCX_SUCCESS;
+                    finished = true;
+                } else if (sqp_it >= o.max_sqp_iter) {
+                    status = MPCX_MAXITER;
+                    finished = true;
+                } else {
+                    state = LS_FACT;
+                    sp.have = false;
+                    qp_it = 0;
+                }
             }
-            if (it >= o.max_sqp_iter) { status = MPCX_MAXITER; break; }
-            int qit = 0;
-            int qs = qp_solve<NH>(L, o, qit);
-            qp_total += qit;
-            ++it;
-            if (qs != 0 && qs != 1) { status = MPCX_QP_FAILURE; break; }
+        }
+
+        // ---- C: interior point, factorisation and predictor --------------------------------
+        if (state == LS_FACT) {
+            sweep_B0<NH>(L, o, sp, m_total, R);
+            int qs = -1;     // HPIPM-style: 0 solved, 1 iteration limit, 3 NaN
+            if (!(finite_d(R.g) && finite_d(R.b) && finite_d(R.d) && finite_d(R.m))) qs = 3;
+            else if (R.g < o.qp_tol_stat && R.b < o.qp_tol_eq && R.d < o.qp_tol_ineq && R.m < o.qp_tol_comp) qs = 0;
+            else if (qp_it >= o.max_qp_iter) qs = 1;
+            if (qs >= 0) {
+                qp_total += qp_it;
+                ++sqp_it;
+                if (qs == 3) {
+                    status = MPCX_QP_FAILURE;
+                    finished = true;
+                } else {
+                    state = LS_LIN;          // the next sweep L applies the step
+                }
+            } else {
+                double S1, S2;
+                a_aff = sweep_F<NH, true>(L, o, 0, 0.0, S1, S2);
+                double S0 = R.mu * (double)m_total;
+                double mu_aff = fma(a_aff, fma(a_aff, S2, S1), S0) / (double)m_total;
+                if (mu_aff < 0.0) mu_aff = 0.0;
+                double ratio = mu_aff / R.mu;
+                double sigma = ratio * ratio * ratio;
+                sigma_mu = sigma * R.mu;
+                mode = 1;
+                state = LS_SOLVE;
+            }
+        }
+
+        // ---- D: corrector; centring-only re-solve where the corrector shortened the step ----
+        // Lanes that need the re-solve run it in a second pass right away when they are at
+        // least a third of the solving lanes; otherwise they keep state LS_SOLVE (mode 2),
+        // sit out the next tick's C and join its D.
+        {
+            bool run = (state == LS_SOLVE);
+            for (int pass = 0; pass < 2; ++pass) {
+                if (!__any(run)) break;
+                double alpha = 0.0;
+                bool again = false;
+                if (run) {
+                    double d1, d2;
+                    sweep_Bs<NH>(L, o, mode, sigma_mu);
+                    alpha = sweep_F<NH, false>(L, o, mode, sigma_mu, d1, d2);
+                    again = (mode == 1) && o.cond_pred_corr && (alpha < a_aff);
+                    if (!again) {
+                        ++qp_it;
+                        if (!(alpha > o.alpha_min)) {      // minimum step or NaN
+                            qp_total += qp_it;
+                            ++sqp_it;
+                            status = MPCX_QP_FAILURE;
+                            finished = true;
+                            state = LS_FETCH;
+                        } else {
+                            sp.have = true;
+                            sp.mode = mode;
+                            sp.sigma_mu = sigma_mu;
+                            sp.alpha = alpha * fma(alpha, 0.9999999, (1.0 - alpha) * 0.99);
+                            state = LS_FACT;
+                        }
+                    } else {
+                        mode = 2;
+                    }
+                }
+                const int n_again = __popcll(__ballot(again));
+                const int n_run = __popcll(__ballot(run));
+                const bool immediate = (3 * n_again >= n_run);
+                run = again && immediate;
+            }
+        }
+
+        // ---- E: results of finished problems ------------------------------------------------
+        if (finished) {
+            const size_t b = L.b;
             for (int k = 0; k <= N; ++k) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    stw(L, k, M::X + i, ldw(L, k, M::X + i) + ldw(L, k, M::V + NU + i));
-                    if (k > 0) stw(L, k, M::PI + i, ldw(L, k, M::QPI + i));
-                }
+                for (int i = 0; i < NX; ++i)
+                    out.X[(b * (size_t)(N + 1) + k) * NX + i] = ldw(L, k, M::X + i);
                 if (k < N) {
-#pragma unroll
-                    for (int c = 0; c < NU; ++c)
-                        stw(L, k, M::U + c, ldw(L, k, M::U + c) + ldw(L, k, M::V + c));
-                }
-                int r0, r1;
-                row_range(L, k, r0, r1);
-#pragma unroll
-                for (int r = 0; r < M::R; ++r) {
-                    if (r < r0 || r >= r1) continue;
-                    stw(L, k, M::NLL + r, ldw(L, k, M::LAML + r));
-                    stw(L, k, M::NLU + r, ldw(L, k, M::LAMU + r));
+                    out.U[(b * (size_t)N + k) * NU + 0] = ldw(L, k, M::U + 0);
+                    out.U[(b * (size_t)N + k) * NU + 1] = ldw(L, k, M::U + 1);
                 }
             }
-            if (o.rti) { status = MPCX_SUCCESS; break; }
-        }
-        // results
-        for (int k = 0; k <= N; ++k) {
+            out.status[b] = status;
+            out.sqp_iter[b] = sqp_it;
+            out.qp_iter[b] = qp_total;
+            out.cost[b] = cost;
 #pragma unroll
-            for (int i = 0; i < NX; ++i)
-                out.X[(b * (size_t)(N + 1) + k) * NX + i] = ldw(L, k, M::X + i);
-            if (k < N) {
-                out.U[(b * (size_t)N + k) * NU + 0] = ldw(L, k, M::U + 0);
-                out.U[(b * (size_t)N + k) * NU + 1] = ldw(L, k, M::U + 1);
-            }
+            for (int i = 0; i < 4; ++i) out.res[(size_t)i * L.B + b] = res[i];
+            state = LS_FETCH;
         }
-        out.status[b] = status;
-        out.sqp_iter[b] = it;
-        out.qp_iter[b] = qp_total;
-        out.cost[b] = nlp_cost<NH>(L);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) out.res[(size_t)i * B + b] = res[i];
     }
 }
 
-// sin/cos and one RK4 step, for the arithmetic parity tests
+// sin/cos as the solver computes them, for the arithmetic parity tests
 __global__ void mpcx_probe_kernel(const double *xin, int n, double *s, double *c)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1150,14 +1423,18 @@ size_t mpcx_stage_doubles(int nh)
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
                            double *workspace, int n_waves, hipStream_t stream)
 {
-    const int n_groups = (in.B + 63) / 64;
+    // the first 256 bytes of the workspace hold the problem counter
+    int *counter = reinterpret_cast<int *>(workspace);
+    double *ws = workspace + 32;
+    hipError_t e = hipMemsetAsync(counter, 0, 256, stream);
+    if (e != hipSuccess) return e;
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, o, out, workspace, n_groups); break;
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, o, out, workspace, n_groups); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, o, out, workspace, n_groups); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, o, out, workspace, n_groups); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, o, out, workspace, n_groups); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, o, out, ws, counter); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, o, out, ws, counter); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, o, out, ws, counter); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, o, out, ws, counter); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, o, out, ws, counter); break;
     }
     return hipGetLastError();
 }

@@ -267,15 +267,16 @@ static void rk4_sens(const problem *pb, const real *x, const real *u,
     }
     model_eval(pb, xs, u, k4, &J);
     vde_eval(&J, Ss, K4);
+    /* weighted sum in the order the stages are produced: ((k1 + 2 k2) + 2 k3) + k4 */
     for (int i = 0; i < NX; ++i) {
-        real t = k1[i] + k4[i];
-        t = rfma((real)2.0, k2[i], t);
+        real t = rfma((real)2.0, k2[i], k1[i]);
         t = rfma((real)2.0, k3[i], t);
+        t = t + k4[i];
         xn[i] = rfma(h6, t, x[i]);
         for (int c = 0; c < NZ; ++c) {
-            real ts = K1[i][c] + K4[i][c];
-            ts = rfma((real)2.0, K2[i][c], ts);
+            real ts = rfma((real)2.0, K2[i][c], K1[i][c]);
             ts = rfma((real)2.0, K3[i][c], ts);
+            ts = ts + K4[i][c];
             real sv = rfma(h6, ts, S0[i][c]);
             if (c < NX) A[i][c] = sv; else Bm[i][c - NX] = sv;
         }
@@ -394,7 +395,9 @@ static void qp_residuals(const problem *pb, stage *st, int m_total, qp_res *R)
 {
     const int N = pb->N;
     real ng = 0.0, nb = 0.0, nd = 0.0, nm = 0.0, sum = 0.0;
-    for (int k = 0; k <= N; ++k) {
+    /* stages are visited last to first (the order in which a backward Riccati
+     * sweep meets them), which fixes the summation order of `sum` */
+    for (int k = N; k >= 0; --k) {
         stage *s = &st[k];
         const real *lo = row_lo(pb, k), *up = row_up(pb, k);
         for (int j = 0; j < NZ; ++j) s->rg[j] = rfma(s->Hd[j], s->v[j], s->g[j]);
@@ -613,9 +616,9 @@ static void riccati_solve(const problem *pb, stage *st)
         const stage *n = &st[k + 1];
         real w[NX], m[NZ];
         for (int i = 0; i < NX; ++i) {
-            real acc = n->p[i];
-            for (int j = 0; j < NX; ++j) acc = rfma(n->P[i][j], s->rb[j], acc);
-            w[i] = acc;
+            real acc = n->P[i][0] * s->rb[0];
+            for (int j = 1; j < NX; ++j) acc = rfma(n->P[i][j], s->rb[j], acc);
+            w[i] = n->p[i] + acc;
         }
         for (int c = 0; c < NZ; ++c) {
             real acc = s->gt[c];
