@@ -116,7 +116,7 @@ int mpcx_device_count(void)
 size_t mpcx_workspace_bytes(int32_t B, int32_t N)
 {
     if (B <= 0 || N < 1) return 0;
-    return 256 + (size_t)waves_for(B) * (size_t)(N + 1) * mpcx_stage_doubles(MPCX_MAX_OBS) * 64 * sizeof(double);
+    return 512 + (size_t)waves_for(B) * (size_t)(N + 1) * mpcx_stage_doubles(MPCX_MAX_OBS) * 64 * sizeof(double);
 }
 
 int mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *out,
@@ -127,7 +127,7 @@ int mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts, mpcx_re
     if (mpcx_device_count() <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
     const int nh = (opts->max_obs < 0) ? MPCX_MAX_OBS : opts->max_obs;
     const int n_waves = waves_for(in->B);
-    const size_t need = 256 + (size_t)n_waves * (size_t)(in->N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
+    const size_t need = 512 + (size_t)n_waves * (size_t)(in->N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
     if (!workspace || workspace_bytes < need)
         return fail(MPCX_E_BADARG, "workspace too small: %zu bytes given, %zu needed", workspace_bytes, need);
     if ((uintptr_t)workspace % 256 != 0) return fail(MPCX_E_BADARG, "workspace not 256-byte aligned");
@@ -161,7 +161,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     const size_t n_pd = (size_t)MPCX_NFIELDS * B, n_xg = (N + 1) * MPCX_NX * B;
     const size_t n_X = B * (N + 1) * MPCX_NX, n_U = B * N * MPCX_NU;
     const int n_waves = waves_for(in->B);
-    const size_t ws_bytes = 256 + (size_t)n_waves * (N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
+    const size_t ws_bytes = 512 + (size_t)n_waves * (N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
 
     DevBuf d_pd, d_no, d_xg, d_X, d_U, d_st, d_si, d_qi, d_co, d_re, d_ws;
     if (d_pd.alloc(n_pd * 8) != hipSuccess || d_no.alloc(B * 4) != hipSuccess ||

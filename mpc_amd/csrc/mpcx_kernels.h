@@ -12,7 +12,7 @@ size_t mpcx_stage_doubles(int nh);
 
 // Launch the fused SQP solve on `n_waves` persistent 64-lane workgroups.  All
 // pointers inside `in` / `out` and `workspace` are device memory; `workspace`
-// holds 256 bytes (problem counter) + n_waves * (N+1) * mpcx_stage_doubles(nh) * 64 doubles.
+// holds 512 bytes (problem counter, options) + n_waves * (N+1) * mpcx_stage_doubles(nh) * 64 doubles.
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
                            double *workspace, int n_waves, hipStream_t stream);
 

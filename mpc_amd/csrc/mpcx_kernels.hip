@@ -44,6 +44,11 @@
 
 #define DEV __device__ __forceinline__
 
+// Pointers that cross a (non-inlined) function boundary carry their address space in the
+// type, so that the callee still emits global_load / ds_read rather than flat accesses.
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(3))) double ldouble;
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -62,11 +67,13 @@ struct Map {
     static constexpr int LAMU = LAML + R;      // R
     static constexpr int TL = LAMU + R;        // R  slacks
     static constexpr int TU = TL + R;          // R
-    static constexpr int RG = TU + R;          // 7  stationarity residual
+    static constexpr int TIL = TU + R;         // R  1 / slack
+    static constexpr int TIU = TIL + R;        // R
+    static constexpr int RG = TIU + R;         // 7  stationarity residual
     static constexpr int RB = RG + 7;          // 5  dynamics residual
     static constexpr int PRB = RB + 5;         // 5  P(k+1) * rb
     static constexpr int K = PRB + 5;          // 10 feedback gain, row-major [2][5]
-    static constexpr int LDL = K + 10;         // 3  l10, d0, d1 of M_uu
+    static constexpr int LDL = K + 10;         // 3  l10, 1/d0, 1/d1 of the LDL' of M_uu
     static constexpr int P = LDL + 3;          // 15 cost-to-go Hessian, lower triangle
     static constexpr int KV = P + 15;          // 2  feed-forward
     static constexpr int PV = KV + 2;          // 5  cost-to-go gradient
@@ -85,9 +92,9 @@ struct AB {
 };
 
 struct Lane {
-    double *wave;         // workspace of this wavefront (same in all lanes); element (k, f)
+    gdouble *wave;        // workspace of this wavefront (same in all lanes); element (k, f)
                           // of lane l is wave[(k*F + f) * 64 + l]
-    const double *pdata;  // problem table (same in all lanes); field f of problem b at [f*B + b]
+    const gdouble *pdata; // problem table (same in all lanes); field f of problem b at [f*B + b]
     size_t B;
     unsigned lane;        // 0..63
     unsigned b;           // problem this lane is solving
@@ -338,50 +345,51 @@ template <int KIND> DEV constexpr bool var_present(int j)   // is v[j] a variabl
     return (j < NU) ? (KIND != LAST) : (KIND != FIRST);
 }
 
-// problem constants of one lane that the row code of stages < N needs; loaded
-// once per sweep (the terminal stage reads its own few directly)
+// Per-lane problem constants live in LDS as [field][lane] (one ds_read_b64 per
+// use, conflict-free), written when the lane takes a problem.  Keeping them out
+// of the vector registers is what lets a whole stage's global loads be in
+// flight at once without spilling.
+enum {
+    C_LBU = 0, C_UBU = 2, C_LBX = 4, C_UBX = 9, C_CG = 14, C_LG = 18, C_UG = 20, C_LH = 22, C_UH = 23,
+    C_GOAL = 24, C_W = 29, C_HW = 36, C_LBXE = 43, C_UBXE = 48, C_WE = 53, C_X0 = 58, C_OBS = 63
+};
+template <int NH> struct PCN { static constexpr int N = C_OBS + 3 * NH; };
+
 template <int NH>
 struct PC {
-    double lbu[NU], ubu[NU], lbx[NX], ubx[NX], cg[4], lg[2], ug[2], lh, uh;
-    double goal[NX], w[NZ], hw[NZ], lmk;
-    double obs[3 * (NH > 0 ? NH : 1)];
+    ldouble *p;         // LDS, already offset by the lane
+    double lmk;
+    DEV double get(int f) const { return p[f * 64]; }
 };
 
 template <int NH>
-DEV void load_pc(const Lane &L, const mpcx_opts &o, PC<NH> &pc)
+DEV void fill_pc(const Lane &L, const mpcx_opts &o, PC<NH> &pc)
 {
-#pragma unroll
-    for (int c = 0; c < NU; ++c) { pc.lbu[c] = ldp(L, MPCX_F_LBU + c); pc.ubu[c] = ldp(L, MPCX_F_UBU + c); }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        pc.lbx[i] = ldp(L, MPCX_F_LBX + i);
-        pc.ubx[i] = ldp(L, MPCX_F_UBX + i);
-        pc.goal[i] = ldp(L, MPCX_F_GOAL + i);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pc.cg[i] = ldp(L, MPCX_F_CG + i);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { pc.lg[i] = ldp(L, MPCX_F_LG + i); pc.ug[i] = ldp(L, MPCX_F_UG + i); }
-    pc.lh = ldp(L, MPCX_F_LH);
-    pc.uh = ldp(L, MPCX_F_UH);
-#pragma unroll
-    for (int j = 0; j < NZ; ++j) { pc.w[j] = ldp(L, MPCX_F_W + j); pc.hw[j] = L.h * pc.w[j]; }
+    auto cp = [&](int dst, int src, int n) {
+        for (int i = 0; i < n; ++i) pc.p[(dst + i) * 64] = ldp(L, src + i);
+    };
+    cp(C_LBU, MPCX_F_LBU, 2);   cp(C_UBU, MPCX_F_UBU, 2);
+    cp(C_LBX, MPCX_F_LBX, 5);   cp(C_UBX, MPCX_F_UBX, 5);
+    cp(C_CG, MPCX_F_CG, 4);     cp(C_LG, MPCX_F_LG, 2);     cp(C_UG, MPCX_F_UG, 2);
+    cp(C_LH, MPCX_F_LH, 1);     cp(C_UH, MPCX_F_UH, 1);
+    cp(C_GOAL, MPCX_F_GOAL, 5); cp(C_W, MPCX_F_W, 7);
+    cp(C_LBXE, MPCX_F_LBXE, 5); cp(C_UBXE, MPCX_F_UBXE, 5); cp(C_WE, MPCX_F_WE, 5);
+    cp(C_X0, MPCX_F_X0, 5);     cp(C_OBS, MPCX_F_OBS, 3 * NH);
+    for (int j = 0; j < NZ; ++j) pc.p[(C_HW + j) * 64] = L.h * ldp(L, MPCX_F_W + j);
     pc.lmk = o.lm_scale_by_h ? L.h * o.lm : o.lm;
-#pragma unroll
-    for (int i = 0; i < 3 * NH; ++i) pc.obs[i] = ldp(L, MPCX_F_OBS + i);
 }
 
 // bounds of row r (terminal state box for KIND == LAST)
 template <int NH, int KIND>
 DEV void row_bounds(const Lane &L, const PC<NH> &pc, int r, double &lo, double &up)
 {
-    if (r < NU) { lo = pc.lbu[r]; up = pc.ubu[r]; }
+    if (r < NU) { lo = pc.get(C_LBU + r); up = pc.get(C_UBU + r); }
     else if (r < ROW_G0) {
-        if (KIND == LAST) { lo = ldp(L, MPCX_F_LBXE + r - NU); up = ldp(L, MPCX_F_UBXE + r - NU); }
-        else { lo = pc.lbx[r - NU]; up = pc.ubx[r - NU]; }
+        if (KIND == LAST) { lo = pc.get(C_LBXE + r - NU); up = pc.get(C_UBXE + r - NU); }
+        else { lo = pc.get(C_LBX + r - NU); up = pc.get(C_UBX + r - NU); }
     }
-    else if (r < 9) { lo = pc.lg[r - ROW_G0]; up = pc.ug[r - ROW_G0]; }
-    else { lo = pc.lh; up = pc.uh; }
+    else if (r < 9) { lo = pc.get(C_LG + r - ROW_G0); up = pc.get(C_UG + r - ROW_G0); }
+    else { lo = pc.get(C_LH); up = pc.get(C_UH); }
 }
 
 // value c of row r at (x, u) and, for general rows, its Jacobian (jx, jy) w.r.t. (x, y)
@@ -394,13 +402,13 @@ DEV void row_geom(const PC<NH> &pc, int r, const double *x, const double *u,
     if (r < NU) c = u[r];
     else if (r < ROW_G0) c = x[r - NU];
     else if (r < 9) {
-        jx = pc.cg[2 * (r - ROW_G0)];
-        jy = pc.cg[2 * (r - ROW_G0) + 1];
+        jx = pc.get(C_CG + 2 * (r - ROW_G0));
+        jy = pc.get(C_CG + 2 * (r - ROW_G0) + 1);
         c = fma(jy, x[1], jx * x[0]);
     } else {
         const int j = (r - 9 < NH) ? r - 9 : 0;
-        double dx = x[0] - pc.obs[3 * j], dy = x[1] - pc.obs[3 * j + 1];
-        c = fma(dy, dy, dx * dx) - pc.obs[3 * j + 2];
+        double dx = x[0] - pc.get(C_OBS + 3 * j), dy = x[1] - pc.get(C_OBS + 3 * j + 1);
+        c = fma(dy, dy, dx * dx) - pc.get(C_OBS + 3 * j + 2);
         jx = 2.0 * dx;
         jy = 2.0 * dy;
     }
@@ -421,18 +429,19 @@ DEV void cost_terms(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, const d
     if (KIND != LAST) {
 #pragma unroll
         for (int j = 0; j < NZ; ++j) {
-            double z = (j < NU) ? u[j] : (x[j - NU] - pc.goal[j - NU]);
-            Hd[j] = pc.hw[j] + pc.lmk;
-            g[j] = pc.hw[j] * z;
+            double z = (j < NU) ? u[j] : (x[j - NU] - pc.get(C_GOAL + j - NU));
+            const double hw = pc.get(C_HW + j);
+            Hd[j] = hw + pc.lmk;
+            g[j] = hw * z;
         }
     } else {
         Hd[0] = Hd[1] = 0.0;
         g[0] = g[1] = 0.0;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            double we = ldp(L, MPCX_F_WE + i);
+            double we = pc.get(C_WE + i);
             Hd[NU + i] = we + o.lm;
-            g[NU + i] = we * (x[i] - pc.goal[i]);
+            g[NU + i] = we * (x[i] - pc.get(C_GOAL + i));
         }
     }
 }
@@ -505,6 +514,7 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
         ll[r] = ldw(L, k, M::LAML + r);
         lu[r] = ldw(L, k, M::LAMU + r);
     }
+    __builtin_amdgcn_sched_barrier(0);
     // SQP step (nothing to add before the first QP; v is uninitialised then)
     AB ab = {};
     if (KIND != LAST) {
@@ -543,7 +553,7 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
     if (KIND == FIRST) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            double d0 = ldp(L, MPCX_F_X0 + i) - xk[i];
+            double d0 = pc.get(C_X0 + i) - xk[i];
             vq[NU + i] = d0;
             a.ri = dmax(a.ri, dabs(d0));
         }
@@ -587,6 +597,8 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
         stw(L, k, M::TU + r, tu);
         stw(L, k, M::LAML + r, mu0 / tl);
         stw(L, k, M::LAMU + r, mu0 / tu);
+        stw(L, k, M::TIL + r, 1.0 / tl);
+        stw(L, k, M::TIU + r, 1.0 / tu);
     }
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
@@ -599,15 +611,15 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
     if (KIND != LAST) {
 #pragma unroll
         for (int j = 0; j < NZ; ++j) {
-            double z = (j < NU) ? uk[j] : (xk[j - NU] - pc.goal[j - NU]);
-            double hw = (0.5 * L.h) * pc.w[j];
+            double z = (j < NU) ? uk[j] : (xk[j - NU] - pc.get(C_GOAL + j - NU));
+            double hw = (0.5 * L.h) * pc.get(C_W + j);
             a.cost = fma(hw * z, z, a.cost);
         }
     } else {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            double z = xk[i] - pc.goal[i];
-            a.cost = fma((0.5 * ldp(L, MPCX_F_WE + i)) * z, z, a.cost);
+            double z = xk[i] - pc.get(C_GOAL + i);
+            a.cost = fma((0.5 * pc.get(C_WE + i)) * z, z, a.cost);
         }
     }
 #pragma unroll
@@ -617,13 +629,15 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
     }
 }
 
+// The sweeps are separate (non-inlined) functions so that each gets its own register
+// allocation; arguments travel by value in registers and results come back through a
+// small per-lane LDS area `ret` ([slot][lane] doubles), never through the stack.
 template <int NH>
-DEV void sweep_L(const Lane &L, const mpcx_opts &o, bool first, double *res, double &cost_out)
+__device__ __attribute__((noinline)) void sweep_L(Lane L, PC<NH> pc, const mpcx_opts *op, bool first, ldouble *ret)
 {
+    const mpcx_opts &o = *op;
     typedef Map<NH> M;
     const int N = L.N;
-    PC<NH> pc;
-    load_pc<NH>(L, o, pc);
     LAcc a = {0.0, 0.0, 0.0, 0.0, 0.0};
     double xk[NX], pik[NX];
 #pragma unroll
@@ -635,8 +649,8 @@ DEV void sweep_L(const Lane &L, const mpcx_opts &o, bool first, double *res, dou
     stage_L<NH, FIRST>(L, o, pc, 0, first, xk, pik, a);
     for (int k = 1; k < N; ++k) stage_L<NH, MID>(L, o, pc, k, first, xk, pik, a);
     stage_L<NH, LAST>(L, o, pc, N, first, xk, pik, a);
-    res[0] = a.rs; res[1] = a.re; res[2] = a.ri; res[3] = a.rc;
-    cost_out = a.cost;
+    ret[0 * 64] = a.rs; ret[1 * 64] = a.re; ret[2 * 64] = a.ri; ret[3 * 64] = a.rc;
+    ret[4 * 64] = a.cost;
 }
 
 // ---------------------------------------------------------------------------
@@ -667,7 +681,7 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
     typedef Map<NH> M;
     // ---- loads ----
     double x[NX], u[NU], v[NZ], vo[NZ], dv[NZ], dva[NZ], qpi[NX], dpi[NX];
-    double ll[M::R], lu[M::R], tl[M::R], tu[M::R];
+    double ll[M::R], lu[M::R], tl[M::R], tu[M::R], til_[M::R], tiu_[M::R];
     load_xu<NH, KIND>(L, k, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
@@ -682,12 +696,14 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
-        ll[r] = lu[r] = tl[r] = tu[r] = 1.0;
+        ll[r] = lu[r] = tl[r] = tu[r] = til_[r] = tiu_[r] = 1.0;
         if (!row_present<KIND>(r)) continue;
         ll[r] = ldw(L, k, M::LAML + r);
         lu[r] = ldw(L, k, M::LAMU + r);
         tl[r] = ldw(L, k, M::TL + r);
         tu[r] = ldw(L, k, M::TU + r);
+        til_[r] = ldw(L, k, M::TIL + r);
+        tiu_[r] = ldw(L, k, M::TIU + r);
     }
     AB ab = {};
     double bv[NX];
@@ -696,6 +712,7 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
 #pragma unroll
         for (int i = 0; i < NX; ++i) bv[i] = ldw(L, k, M::BV + i);
     }
+    __builtin_amdgcn_sched_barrier(0);     // every load of the stage is in flight before the first use
     // ---- pending step on the primal and the dynamics multiplier ----
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
@@ -738,7 +755,7 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
             double jvo = jdot(r, jx, jy, vo);
             double rdl = (dlo - jvo) + t_l;
             double rdu = (jvo - dup) + t_u;
-            double til = 1.0 / t_l, tiu = 1.0 / t_u;
+            double til = til_[r], tiu = tiu_[r];
             double jda = jdot(r, jx, jy, dva);
             double rml, rmu;
             row_rm(sp.mode, sp.sigma_mu, jda, l_l, l_u, t_l, t_u, til, tiu, rdl, rdu, rml, rmu);
@@ -775,6 +792,8 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
         cy.sum = pr ? sum : cy.sum;
         // affine right-hand side and barrier Hessian
         double til = 1.0 / t_l, tiu = 1.0 / t_u;
+        stw(L, k, M::TIL + r, til);
+        stw(L, k, M::TIU + r, tiu);
         double ql = fma(-l_l, rdl, ml) * til;
         double qu = fma(-l_u, rdu, mu_) * tiu;
         qrow[r] = ql - qu;
@@ -874,9 +893,9 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
                 Mm[r][c] = acc;
             }
         }
-        const double d0 = Mm[0][0];
-        const double l10 = Mm[1][0] / d0;
-        const double d1 = fma(-l10, Mm[1][0], Mm[1][1]);
+        const double d0 = 1.0 / Mm[0][0];                          // reciprocal pivots
+        const double l10 = Mm[1][0] * d0;
+        const double d1 = 1.0 / fma(-l10, Mm[1][0], Mm[1][1]);
         stw(L, k, M::LDL + 0, l10);
         stw(L, k, M::LDL + 1, d0);
         stw(L, k, M::LDL + 2, d1);
@@ -885,7 +904,7 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
         for (int i = 0; i < NX; ++i) {
             double y0 = Mm[NU + i][0];
             double y1 = fma(-l10, y0, Mm[NU + i][1]);
-            double z0 = y0 / d0, z1 = y1 / d1;
+            double z0 = y0 * d0, z1 = y1 * d1;
             double s0 = fma(-l10, z1, z0);
             Kg[0][i] = -s0;
             Kg[1][i] = -z1;
@@ -900,7 +919,7 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
         {
             double y0 = m[0];
             double y1 = fma(-l10, y0, m[1]);
-            double z0 = y0 / d0, z1 = y1 / d1;
+            double z0 = y0 * d0, z1 = y1 * d1;
             double s0 = fma(-l10, z1, z0);
             stw(L, k, M::KV + 0, -s0);
             stw(L, k, M::KV + 1, -z1);
@@ -928,11 +947,13 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
 }
 
 template <int NH>
-DEV void sweep_B0(const Lane &L, const mpcx_opts &o, const Step &sp, int m_total, QpRes &R)
+__device__ __attribute__((noinline)) void sweep_B0(Lane L, PC<NH> pc, const mpcx_opts *op, bool sp_have, int sp_mode,
+                                                   double sp_sigma_mu, double sp_alpha, int m_total, ldouble *ret)
 {
+    const mpcx_opts &o = *op;
+    Step sp;
+    sp.have = sp_have; sp.mode = sp_mode; sp.sigma_mu = sp_sigma_mu; sp.alpha = sp_alpha;
     const int N = L.N;
-    PC<NH> pc;
-    load_pc<NH>(L, o, pc);
     B0Carry cy;
 #pragma unroll
     for (int i = 0; i < NX; ++i) { cy.pn[i] = 0.0; cy.vxn[i] = 0.0; cy.qpin[i] = 0.0; }
@@ -942,8 +963,8 @@ DEV void sweep_B0(const Lane &L, const mpcx_opts &o, const Step &sp, int m_total
     stage_B0<NH, LAST>(L, o, pc, N, sp, cy);
     for (int k = N - 1; k >= 1; --k) stage_B0<NH, MID>(L, o, pc, k, sp, cy);
     stage_B0<NH, FIRST>(L, o, pc, 0, sp, cy);
-    R.g = cy.ng; R.b = cy.nb; R.d = cy.nd; R.m = cy.nm;
-    R.mu = cy.sum / (double)m_total;
+    ret[0 * 64] = cy.ng; ret[1 * 64] = cy.nb; ret[2 * 64] = cy.nd; ret[3 * 64] = cy.nm;
+    ret[4 * 64] = cy.sum / (double)m_total;
 }
 
 // Bs: new right-hand side (mode 1 corrector, mode 2 centring), backward
@@ -954,7 +975,7 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, in
 {
     typedef Map<NH> M;
     double x[NX], u[NU], v[NZ], dva[NZ], gt[NZ];
-    double ll[M::R], lu[M::R], tl[M::R], tu[M::R];
+    double ll[M::R], lu[M::R], tl[M::R], tu[M::R], til_[M::R], tiu_[M::R];
     load_xu<NH, KIND>(L, k, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
@@ -964,12 +985,14 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, in
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
-        ll[r] = lu[r] = tl[r] = tu[r] = 1.0;
+        ll[r] = lu[r] = tl[r] = tu[r] = til_[r] = tiu_[r] = 1.0;
         if (!row_present<KIND>(r)) continue;
         ll[r] = ldw(L, k, M::LAML + r);
         lu[r] = ldw(L, k, M::LAMU + r);
         tl[r] = ldw(L, k, M::TL + r);
         tu[r] = ldw(L, k, M::TU + r);
+        til_[r] = ldw(L, k, M::TIL + r);
+        tiu_[r] = ldw(L, k, M::TIU + r);
     }
     AB ab = {};
     double prb[NX], l10 = 0.0, d0 = 1.0, d1 = 1.0, k0[NX], k1[NX];
@@ -985,6 +1008,7 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, in
         d0 = ldw(L, k, M::LDL + 1);
         d1 = ldw(L, k, M::LDL + 2);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
         if (!row_present<KIND>(r)) continue;
@@ -996,7 +1020,7 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, in
         double jv = jdot(r, jx, jy, v);
         double rdl = (dlo - jv) + tl[r];
         double rdu = (jv - dup) + tu[r];
-        double til = 1.0 / tl[r], tiu = 1.0 / tu[r];
+        double til = til_[r], tiu = tiu_[r];
         double jda = jdot(r, jx, jy, dva);
         double rml, rmu;
         row_rm(mode, sigma_mu, jda, ll[r], lu[r], tl[r], tu[r], til, tiu, rdl, rdu, rml, rmu);
@@ -1021,7 +1045,7 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, in
         add_BAt(L, ab, w, m);
         double y0 = m[0];
         double y1 = fma(-l10, y0, m[1]);
-        double z0 = y0 / d0, z1 = y1 / d1;
+        double z0 = y0 * d0, z1 = y1 * d1;
         double s0 = fma(-l10, z1, z0);
         stw(L, k, M::KV + 0, -s0);
         stw(L, k, M::KV + 1, -z1);
@@ -1035,11 +1059,10 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, in
 }
 
 template <int NH>
-DEV void sweep_Bs(const Lane &L, const mpcx_opts &o, int mode, double sigma_mu)
+__device__ __attribute__((noinline)) void sweep_Bs(Lane L, PC<NH> pc, const mpcx_opts *op, int mode, double sigma_mu)
 {
+    const mpcx_opts &o = *op;
     const int N = L.N;
-    PC<NH> pc;
-    load_pc<NH>(L, o, pc);
     double pn[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) pn[i] = 0.0;
@@ -1053,7 +1076,9 @@ DEV void sweep_Bs(const Lane &L, const mpcx_opts &o, int mode, double sigma_mu)
 // feasible length and the centring sums.  Otherwise (mode 1 or 2 per lane):
 // stores the step (DV, DPI) and returns its longest feasible length.
 // ---------------------------------------------------------------------------
-struct FAcc { double alpha, s1, s2; };
+// the longest feasible step is num/den: the smallest ratio met so far, kept as a pair and
+// compared by cross multiplication so that a sweep needs one division only
+struct FAcc { double num, den, s1, s2; };
 
 template <int NH, int KIND, bool AFFINE>
 DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int mode, double sigma_mu,
@@ -1061,7 +1086,7 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int
 {
     typedef Map<NH> M;
     double x[NX], u[NU], v[NZ], dva[NZ], dvk[NZ], dxn[NX];
-    double ll[M::R], lu[M::R], tl[M::R], tu[M::R];
+    double ll[M::R], lu[M::R], tl[M::R], tu[M::R], til_[M::R], tiu_[M::R];
     load_xu<NH, KIND>(L, k, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
@@ -1070,12 +1095,14 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
-        ll[r] = lu[r] = tl[r] = tu[r] = 1.0;
+        ll[r] = lu[r] = tl[r] = tu[r] = til_[r] = tiu_[r] = 1.0;
         if (!row_present<KIND>(r)) continue;
         ll[r] = ldw(L, k, M::LAML + r);
         lu[r] = ldw(L, k, M::LAMU + r);
         tl[r] = ldw(L, k, M::TL + r);
         tu[r] = ldw(L, k, M::TU + r);
+        til_[r] = ldw(L, k, M::TIL + r);
+        tiu_[r] = ldw(L, k, M::TIU + r);
     }
     AB ab = {};
     double rb[NX], kv[NU], kg[NU][NX], pv[NX], Pk[15];
@@ -1096,6 +1123,7 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int
 #pragma unroll
         for (int i = 0; i < 15; ++i) Pk[i] = ldw(L, k, M::P + i);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NX; ++i) { dvk[NU + i] = dx[i]; dxn[i] = 0.0; }
     dvk[0] = dvk[1] = 0.0;
@@ -1132,7 +1160,7 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int
         double jv = jdot(r, jx, jy, v);
         double rdl = (dlo - jv) + tl[r];
         double rdu = (jv - dup) + tu[r];
-        double til = 1.0 / tl[r], tiu = 1.0 / tu[r];
+        double til = til_[r], tiu = tiu_[r];
         double jda = AFFINE ? 0.0 : jdot(r, jx, jy, dva);
         double rml, rmu;
         if (AFFINE) { rml = ll[r] * tl[r]; rmu = lu[r] * tu[r]; }
@@ -1142,12 +1170,13 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int
         double dtu = -jd - rdu;
         double dll = -(fma(ll[r], dtl, rml) * til);
         double dlu = -(fma(lu[r], dtu, rmu) * tiu);
-        double al = a.alpha;
-        { double cnd = -ll[r] / dll; al = (dll < 0.0 && cnd < al) ? cnd : al; }
-        { double cnd = -tl[r] / dtl; al = (dtl < 0.0 && cnd < al) ? cnd : al; }
-        { double cnd = -lu[r] / dlu; al = (dlu < 0.0 && cnd < al) ? cnd : al; }
-        { double cnd = -tu[r] / dtu; al = (dtu < 0.0 && cnd < al) ? cnd : al; }
-        a.alpha = pr ? al : a.alpha;
+        double num = a.num, den = a.den;
+        { const bool c = (dll < 0.0) && (ll[r] * den < num * (-dll)); num = c ? ll[r] : num; den = c ? -dll : den; }
+        { const bool c = (dtl < 0.0) && (tl[r] * den < num * (-dtl)); num = c ? tl[r] : num; den = c ? -dtl : den; }
+        { const bool c = (dlu < 0.0) && (lu[r] * den < num * (-dlu)); num = c ? lu[r] : num; den = c ? -dlu : den; }
+        { const bool c = (dtu < 0.0) && (tu[r] * den < num * (-dtu)); num = c ? tu[r] : num; den = c ? -dtu : den; }
+        a.num = pr ? num : a.num;
+        a.den = pr ? den : a.den;
         if (AFFINE) {
             double s1 = a.s1, s2 = a.s2;
             s1 = fma(ll[r], dtl, s1);
@@ -1165,21 +1194,19 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int
 }
 
 template <int NH, bool AFFINE>
-DEV double sweep_F(const Lane &L, const mpcx_opts &o, int mode, double sigma_mu, double &S1, double &S2)
+__device__ __attribute__((noinline)) double sweep_F(Lane L, PC<NH> pc, const mpcx_opts *op, int mode, double sigma_mu, ldouble *ret)
 {
+    const mpcx_opts &o = *op;
     const int N = L.N;
-    PC<NH> pc;
-    load_pc<NH>(L, o, pc);
-    FAcc a = {1.0, 0.0, 0.0};
+    FAcc a = {1.0, 1.0, 0.0, 0.0};
     double dx[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) dx[i] = 0.0;
     stage_F<NH, FIRST, AFFINE>(L, o, pc, 0, mode, sigma_mu, dx, a);
     for (int k = 1; k < N; ++k) stage_F<NH, MID, AFFINE>(L, o, pc, k, mode, sigma_mu, dx, a);
     stage_F<NH, LAST, AFFINE>(L, o, pc, N, mode, sigma_mu, dx, a);
-    S1 = a.s1;
-    S2 = a.s2;
-    return a.alpha;
+    if (AFFINE) { ret[0 * 64] = a.s1; ret[1 * 64] = a.s2; }
+    return a.num / a.den;
 }
 
 // ---------------------------------------------------------------------------
@@ -1190,6 +1217,28 @@ DEV double sweep_F(const Lane &L, const mpcx_opts &o, int mode, double sigma_mu,
 // need very different numbers of iterations.  Which lane solves which problem
 // does not influence any result.
 // ---------------------------------------------------------------------------
+// Diagnostic build only (-DMPCX_STAMPS): per-wavefront cycle sums of each phase
+// of the tick loop, read back by mpcx_debug_read_stamps().  No stamp code is
+// compiled into the shipped library.
+#ifdef MPCX_STAMPS
+#define N_STAMP 24
+__device__ unsigned long long g_stamps[2048][N_STAMP];
+#define STAMP_BEGIN() unsigned long long st_t0 = __builtin_amdgcn_s_memtime()
+#define STAMP(slot, pred)                                                              \
+    do {                                                                               \
+        unsigned long long st_t1 = __builtin_amdgcn_s_memtime();                       \
+        unsigned long long st_n = __popcll(__ballot(pred));                            \
+        if (threadIdx.x == 0) {                                                        \
+            g_stamps[blockIdx.x][2 * (slot)] += st_t1 - st_t0;                         \
+            g_stamps[blockIdx.x][2 * (slot) + 1] += st_n;                              \
+        }                                                                              \
+        st_t0 = __builtin_amdgcn_s_memtime();                                          \
+    } while (0)
+#else
+#define STAMP_BEGIN() ((void)0)
+#define STAMP(slot, pred) ((void)0)
+#endif
+
 enum LaneState {
     LS_FETCH = 0,   // needs a problem
     LS_LIN = 1,     // needs sweep L (new SQP iteration)
@@ -1200,16 +1249,23 @@ enum LaneState {
 
 template <int NH>
 __global__ void __launch_bounds__(64)
-mpcx_sqp_kernel(mpcx_batch in, mpcx_opts o, mpcx_result out, double *workspace, int *counter)
+mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter)
 {
+    const mpcx_opts &o = *op;
     typedef Map<NH> M;
     const int N = in.N;
     const unsigned B = (unsigned)in.B;
     const size_t wave_doubles = (size_t)(N + 1) * M::F * 64;
 
+    __shared__ double pc_lds[(PCN<NH>::N + 5) * 64];
+    PC<NH> pc;
+    pc.p = (ldouble *)pc_lds + threadIdx.x;
+    pc.lmk = 0.0;
+    ldouble *ret = (ldouble *)pc_lds + PCN<NH>::N * 64 + threadIdx.x;     // results of the sweeps
+
     Lane L;
-    L.wave = workspace + (size_t)blockIdx.x * wave_doubles;
-    L.pdata = in.pdata;
+    L.wave = (gdouble *)workspace + (size_t)blockIdx.x * wave_doubles;
+    L.pdata = (const gdouble *)in.pdata;
     L.B = (size_t)in.B;
     L.lane = threadIdx.x;
     L.b = 0;
@@ -1228,6 +1284,8 @@ mpcx_sqp_kernel(mpcx_batch in, mpcx_opts o, mpcx_result out, double *workspace, 
     sp.have = false; sp.mode = 0; sp.sigma_mu = 0.0; sp.alpha = 0.0;
 
     for (;;) {
+        STAMP_BEGIN();
+        const bool st_a = (state == LS_FETCH);
         // ---- A: take a problem, write the initial iterate -------------------------------
         if (state == LS_FETCH) {
             unsigned b = (unsigned)atomicAdd(counter, 1);
@@ -1247,6 +1305,7 @@ mpcx_sqp_kernel(mpcx_batch in, mpcx_opts o, mpcx_result out, double *workspace, 
                     L.h6 = L.h / 6.0;
                     L.hB = L.h6 * 6.0;
                     L.invL = 1.0 / ldp(L, MPCX_F_L);
+                    fill_pc<NH>(L, o, pc);
                     // row sides: stage 0 has the 2 input rows, stages 1..N-1 all rows, stage N 7 rows
                     m_total = 2 * (NU + (N - 1) * (9 + nobs) + 7);
                     for (int k = 0; k <= N; ++k) {
@@ -1272,18 +1331,23 @@ mpcx_sqp_kernel(mpcx_batch in, mpcx_opts o, mpcx_result out, double *workspace, 
             }
         }
         if (!__any(state != LS_DONE)) break;
+        STAMP(0, st_a);
 
         // ---- B: SQP level -----------------------------------------------------------------
         bool finished = false;
+        const bool st_b = (state == LS_LIN);
         if (state == LS_LIN) {
             if (o.rti && !first) {
                 // real-time iteration: apply the one step, report the new objective
-                double res_after[4];
-                sweep_L<NH>(L, o, false, res_after, cost);
+                sweep_L<NH>(L, pc, op, false, ret);
+                cost = ret[4 * 64];
                 status = MPCX_SUCCESS;
                 finished = true;
             } else {
-                sweep_L<NH>(L, o, first, res, cost);
+                sweep_L<NH>(L, pc, op, first, ret);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) res[i] = ret[i * 64];
+                cost = ret[4 * 64];
                 first = false;
                 if (!(finite_d(res[0]) && finite_d(res[1]) && finite_d(res[2]) && finite_d(res[3]))) {
                     status = MPCX_NAN;
@@ -1303,9 +1367,15 @@ mpcx_sqp_kernel(mpcx_batch in, mpcx_opts o, mpcx_result out, double *workspace, 
             }
         }
 
+        STAMP(1, st_b);
         // ---- C: interior point, factorisation and predictor --------------------------------
+        const bool st_c = (state == LS_FACT);
         if (state == LS_FACT) {
-            sweep_B0<NH>(L, o, sp, m_total, R);
+            sweep_B0<NH>(L, pc, op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, m_total, ret);
+            R.g = ret[0 * 64]; R.b = ret[1 * 64]; R.d = ret[2 * 64]; R.m = ret[3 * 64]; R.mu = ret[4 * 64];
+        }
+        STAMP(2, st_c);
+        if (state == LS_FACT) {
             int qs = -1;     // HPIPM-style: 0 solved, 1 iteration limit, 3 NaN
             if (!(finite_d(R.g) && finite_d(R.b) && finite_d(R.d) && finite_d(R.m))) qs = 3;
             else if (R.g < o.qp_tol_stat && R.b < o.qp_tol_eq && R.d < o.qp_tol_ineq && R.m < o.qp_tol_comp) qs = 0;
@@ -1320,8 +1390,8 @@ mpcx_sqp_kernel(mpcx_batch in, mpcx_opts o, mpcx_result out, double *workspace, 
                     state = LS_LIN;          // the next sweep L applies the step
                 }
             } else {
-                double S1, S2;
-                a_aff = sweep_F<NH, true>(L, o, 0, 0.0, S1, S2);
+                a_aff = sweep_F<NH, true>(L, pc, op, 0, 0.0, ret);
+                const double S1 = ret[0 * 64], S2 = ret[1 * 64];
                 double S0 = R.mu * (double)m_total;
                 double mu_aff = fma(a_aff, fma(a_aff, S2, S1), S0) / (double)m_total;
                 if (mu_aff < 0.0) mu_aff = 0.0;
@@ -1333,6 +1403,7 @@ mpcx_sqp_kernel(mpcx_batch in, mpcx_opts o, mpcx_result out, double *workspace, 
             }
         }
 
+        STAMP(3, st_c);
         // ---- D: corrector; centring-only re-solve where the corrector shortened the step ----
         // Lanes that need the re-solve run it in a second pass right away when they are at
         // least a third of the solving lanes; otherwise they keep state LS_SOLVE (mode 2),
@@ -1343,10 +1414,10 @@ mpcx_sqp_kernel(mpcx_batch in, mpcx_opts o, mpcx_result out, double *workspace, 
                 if (!__any(run)) break;
                 double alpha = 0.0;
                 bool again = false;
+                if (run) sweep_Bs<NH>(L, pc, op, mode, sigma_mu);
+                STAMP(4 + 2 * pass, run);
                 if (run) {
-                    double d1, d2;
-                    sweep_Bs<NH>(L, o, mode, sigma_mu);
-                    alpha = sweep_F<NH, false>(L, o, mode, sigma_mu, d1, d2);
+                    alpha = sweep_F<NH, false>(L, pc, op, mode, sigma_mu, ret);
                     again = (mode == 1) && o.cond_pred_corr && (alpha < a_aff);
                     if (!again) {
                         ++qp_it;
@@ -1367,6 +1438,7 @@ mpcx_sqp_kernel(mpcx_batch in, mpcx_opts o, mpcx_result out, double *workspace, 
                         mode = 2;
                     }
                 }
+                STAMP(5 + 2 * pass, run);
                 const int n_again = __popcll(__ballot(again));
                 const int n_run = __popcll(__ballot(run));
                 const bool immediate = (3 * n_again >= n_run);
@@ -1394,8 +1466,12 @@ mpcx_sqp_kernel(mpcx_batch in, mpcx_opts o, mpcx_result out, double *workspace, 
             for (int i = 0; i < 4; ++i) out.res[(size_t)i * L.B + b] = res[i];
             state = LS_FETCH;
         }
+        STAMP(8, finished);
+        STAMP(9, state != LS_DONE);      // lanes-sum / 64 = ticks; lanes that still have work
+        STAMP(10, true);
     }
 }
+
 
 // sin/cos as the solver computes them, for the arithmetic parity tests
 __global__ void mpcx_probe_kernel(const double *xin, int n, double *s, double *c)
@@ -1423,21 +1499,42 @@ size_t mpcx_stage_doubles(int nh)
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
                            double *workspace, int n_waves, hipStream_t stream)
 {
-    // the first 256 bytes of the workspace hold the problem counter
+    // workspace header (512 bytes): problem counter at byte 0, the options at byte 256
+    static_assert(sizeof(mpcx_opts) <= 256, "options must fit the workspace header");
     int *counter = reinterpret_cast<int *>(workspace);
-    double *ws = workspace + 32;
+    mpcx_opts *d_opts = reinterpret_cast<mpcx_opts *>(reinterpret_cast<char *>(workspace) + 256);
+    double *ws = workspace + 64;
     hipError_t e = hipMemsetAsync(counter, 0, 256, stream);
+    if (e != hipSuccess) return e;
+    // the source is read when the copy is enqueued only if it is pageable host memory, which `o` is
+    e = hipMemcpyAsync(d_opts, &o, sizeof(mpcx_opts), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return e;
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, o, out, ws, counter); break;
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, o, out, ws, counter); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, o, out, ws, counter); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, o, out, ws, counter); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, o, out, ws, counter); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter); break;
+#ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter); break;
+#else
+    default: return hipErrorInvalidValue;
+#endif
     }
     return hipGetLastError();
 }
+
+#ifdef MPCX_STAMPS
+extern "C" int mpcx_debug_read_stamps(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long zeros[2048][N_STAMP];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof(zeros)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 hipError_t mpcx_launch_probe(const double *xin, int n, double *s, double *c, hipStream_t stream)
 {

@@ -180,7 +180,7 @@ typedef struct {
     /* Newton system */
     real Ht[NZ], hxx, hxy, hyy;        /* barrier Hessian: diagonal + (x,y) block */
     real gt[NZ];
-    real K[NU][NX], kv[NU], l10, d0, d1;
+    real K[NU][NX], kv[NU], l10, d0, d1;   /* d0, d1: RECIPROCALS of the pivots of M_uu */
     real P[NX][NX], p[NX];             /* full symmetric storage */
     real dv[NZ], dpi[NX];
     real dva[NZ];                       /* affine (predictor) step */
@@ -584,13 +584,14 @@ static void riccati_factor(const problem *pb, stage *st)
                     acc = rfma((r < NU) ? s->B[i][r] : s->A[i][r - NU], PBA[i][c], acc);
                 M[r][c] = acc;
             }
-        s->d0 = M[0][0];
-        s->l10 = M[1][0] / s->d0;
-        s->d1 = rfma(-s->l10, M[1][0], M[1][1]);
+        /* LDL' of M_uu; the two pivots are inverted once and multiplied with from then on */
+        s->d0 = (real)1.0 / M[0][0];
+        s->l10 = M[1][0] * s->d0;
+        s->d1 = (real)1.0 / rfma(-s->l10, M[1][0], M[1][1]);
         for (int i = 0; i < NX; ++i) {
             real y0 = M[NU + i][0];
             real y1 = rfma(-s->l10, y0, M[NU + i][1]);
-            real z0 = y0 / s->d0, z1 = y1 / s->d1;
+            real z0 = y0 * s->d0, z1 = y1 * s->d1;
             real s1 = z1;
             real s0 = rfma(-s->l10, s1, z0);
             s->K[0][i] = -s0;
@@ -628,7 +629,7 @@ static void riccati_solve(const problem *pb, stage *st)
         }
         real y0 = m[0];
         real y1 = rfma(-s->l10, y0, m[1]);
-        real z0 = y0 / s->d0, z1 = y1 / s->d1;
+        real z0 = y0 * s->d0, z1 = y1 * s->d1;
         real s1 = z1;
         real s0 = rfma(-s->l10, s1, z0);
         s->kv[0] = -s0;
@@ -667,7 +668,11 @@ static real qp_step_length(const problem *pb, stage *st, int mode, real sigma_mu
                            real *S1, real *S2)
 {
     const int N = pb->N;
-    real alpha = 1.0, s1 = 0.0, s2 = 0.0;
+    /* The longest feasible step is the smallest ratio n/d over the sides that
+     * move towards zero (n = current value, d = -step > 0).  The running
+     * minimum is kept as the pair (num, den) and candidates are compared by
+     * cross multiplication, so the whole sweep costs one division. */
+    real num = 1.0, den = 1.0, s1 = 0.0, s2 = 0.0;
     for (int k = 0; k <= N; ++k) {
         stage *s = &st[k];
         for (int r = s->r0; r < s->r1; ++r) {
@@ -690,10 +695,10 @@ static real qp_step_length(const problem *pb, stage *st, int mode, real sigma_mu
             real dtu = -jd - s->rd_u[r];
             real dll = -(rfma(s->lam_l[r], dtl, rml) * til);
             real dlu = -(rfma(s->lam_u[r], dtu, rmu) * tiu);
-            if (dll < (real)0.0) { real c = -s->lam_l[r] / dll; if (c < alpha) { alpha = c; if (g_debug > 1) fprintf(stderr, "      block k=%d r=%d lam_l=%.3e dlam=%.3e t=%.3e\n", k, r, R2D(s->lam_l[r]), R2D(dll), R2D(s->t_l[r])); } }
-            if (dtl < (real)0.0) { real c = -s->t_l[r] / dtl; if (c < alpha) { alpha = c; if (g_debug > 1) fprintf(stderr, "      block k=%d r=%d t_l=%.3e dt=%.3e lam=%.3e\n", k, r, R2D(s->t_l[r]), R2D(dtl), R2D(s->lam_l[r])); } }
-            if (dlu < (real)0.0) { real c = -s->lam_u[r] / dlu; if (c < alpha) { alpha = c; if (g_debug > 1) fprintf(stderr, "      block k=%d r=%d lam_u=%.3e dlam=%.3e t=%.3e\n", k, r, R2D(s->lam_u[r]), R2D(dlu), R2D(s->t_u[r])); } }
-            if (dtu < (real)0.0) { real c = -s->t_u[r] / dtu; if (c < alpha) { alpha = c; if (g_debug > 1) fprintf(stderr, "      block k=%d r=%d t_u=%.3e dt=%.3e lam=%.3e\n", k, r, R2D(s->t_u[r]), R2D(dtu), R2D(s->lam_u[r])); } }
+            if (dll < (real)0.0 && s->lam_l[r] * den < num * (-dll)) { num = s->lam_l[r]; den = -dll; }
+            if (dtl < (real)0.0 && s->t_l[r] * den < num * (-dtl)) { num = s->t_l[r]; den = -dtl; }
+            if (dlu < (real)0.0 && s->lam_u[r] * den < num * (-dlu)) { num = s->lam_u[r]; den = -dlu; }
+            if (dtu < (real)0.0 && s->t_u[r] * den < num * (-dtu)) { num = s->t_u[r]; den = -dtu; }
             s1 = rfma(s->lam_l[r], dtl, s1);
             s1 = rfma(s->t_l[r], dll, s1);
             s1 = rfma(s->lam_u[r], dtu, s1);
@@ -704,7 +709,7 @@ static real qp_step_length(const problem *pb, stage *st, int mode, real sigma_mu
     }
     if (S1) *S1 = s1;
     if (S2) *S2 = s2;
-    return alpha;
+    return num / den;
 }
 
 static void qp_update(const problem *pb, const mpcx_opts *o, stage *st, int mode,

@@ -1,0 +1,44 @@
+"""Per-phase cycle shares of the tick loop (diagnostic build libmpcx_stamps.so).
+
+Usage on the GPU box:  python profiles/stamps.py [batch]
+Prints, per phase, the share of wavefront cycles and the mean number of lanes
+that took part each time the phase ran.
+"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mpc_amd import _lib  # noqa: E402
+from mpc_amd.synthetic import synthetic_batch  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+lib = _lib.load_library(os.path.join(ROOT, "mpc_amd", "csrc", "libmpcx_stamps.so"))
+_lib._lib = lib
+packed = synthetic_batch(B)
+t0 = time.time()
+out = _lib.solve_packed(packed)
+dt = time.time() - t0
+NS = 24
+buf = np.zeros((2048, NS), dtype=np.uint64)
+lib.mpcx_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
+assert lib.mpcx_debug_read_stamps(buf.ctypes.data, 1) == 0
+names = ["A fetch+init", "B sweep L", "C sweep B0", "C sweep F0", "D pass0 Bs", "D pass0 F",
+         "D pass1 Bs", "D pass1 F", "E write-out", "busy lanes", "ticks*64"]
+cyc = buf[:, 0::2].astype(np.float64)
+cnt = buf[:, 1::2].astype(np.float64)
+used = cyc.sum(1) > 0
+print(f"B={B} wall {dt:.2f}s (incl. transfers); waves with work: {used.sum()}")
+tot = cyc[used].sum()
+ticks = None
+for i, n in enumerate(names):
+    c = cyc[used, i].sum()
+    print(f"{n:14s} share {100 * c / tot:5.1f}%   lanes-sum {cnt[used, i].sum():.3g}")
+print("cycles per wave (mean) %.3g  (100 MHz ticks => %.3f s)" % (cyc[used].sum(1).mean(), cyc[used].sum(1).mean() / 1e8))
+w = cyc[used].sum(1)
+print("cycles per wave: min %.3g median %.3g p90 %.3g max %.3g" % (w.min(), np.median(w), np.percentile(w, 90), w.max()))
+print("qp_iter sum", int(out["qp_iter"].sum()), "sqp_iter sum", int(out["sqp_iter"].sum()))
