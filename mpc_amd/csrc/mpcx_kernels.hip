@@ -80,7 +80,15 @@ struct Map {
     static constexpr int DV = PV + 5;          // 7  step
     static constexpr int DPI = DV + 7;         // 5
     static constexpr int DVA = DPI + 5;        // 7  affine (predictor) step
-    static constexpr int F = DVA + 7;
+    // the centring-only solution, computed alongside the corrector one; same order and
+    // distance as KV..DPI so that "solution 2" is "solution 1" + SOL2
+    static constexpr int KV2 = DVA + 7;        // 2
+    static constexpr int PV2 = KV2 + 2;        // 5
+    static constexpr int DV2 = PV2 + 5;        // 7
+    static constexpr int DPI2 = DV2 + 7;       // 5
+    static constexpr int SOL2 = KV2 - KV;
+    static constexpr int F = DPI2 + 5;
+    static_assert(PV2 - PV == SOL2 && DV2 - DV == SOL2 && DPI2 - DPI == SOL2, "solution 2 layout");
 };
 
 // A = dPhi/dx and B = dPhi/du of one RK4 step have this pattern (h* = 6*(h/6)):
@@ -109,6 +117,8 @@ struct Lane {
 DEV double ldw(const Lane &L, int k, int f) { return (L.wave + ((size_t)k * L.F + f) * 64)[L.lane]; }
 DEV void stw(const Lane &L, int k, int f, double v) { (L.wave + ((size_t)k * L.F + f) * 64)[L.lane] = v; }
 DEV double ldp(const Lane &L, int f) { return (L.pdata + (size_t)f * L.B)[L.b]; }
+// field f + df where df differs from lane to lane
+DEV double ldw_lane(const Lane &L, int k, int f, int df) { return (L.wave + ((size_t)k * L.F + f) * 64)[L.lane + 64u * (unsigned)df]; }
 
 DEV double dabs(double a) { return (a < 0.0) ? -a : a; }
 DEV double dmax(double a, double b) { return (b > a) ? b : a; }
@@ -680,19 +690,21 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
 {
     typedef Map<NH> M;
     // ---- loads ----
+    const int sol = (sp.mode == 2) ? M::SOL2 : 0;      // which of the two stored solutions is the step
+    double ssum = 0.0;
     double x[NX], u[NU], v[NZ], vo[NZ], dv[NZ], dva[NZ], qpi[NX], dpi[NX];
     double ll[M::R], lu[M::R], tl[M::R], tu[M::R], til_[M::R], tiu_[M::R];
     load_xu<NH, KIND>(L, k, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
         vo[j] = ldw(L, k, M::V + j);
-        dv[j] = ldw(L, k, M::DV + j);
+        dv[j] = ldw_lane(L, k, M::DV + j, sol);
         dva[j] = ldw(L, k, M::DVA + j);
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         qpi[i] = (KIND != FIRST) ? ldw(L, k, M::QPI + i) : 0.0;
-        dpi[i] = (KIND != FIRST) ? ldw(L, k, M::DPI + i) : 0.0;
+        dpi[i] = (KIND != FIRST) ? ldw_lane(L, k, M::DPI + i, sol) : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
@@ -786,10 +798,10 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
         double nd = dmax(dmax(cy.nd, dabs(rdl)), dabs(rdu));
         double ml = l_l * t_l, mu_ = l_u * t_u;
         double nm = dmax(dmax(cy.nm, dabs(ml)), dabs(mu_));
-        double sum = (cy.sum + ml) + mu_;
+        double sum = (ssum + ml) + mu_;
         cy.nd = pr ? nd : cy.nd;
         cy.nm = pr ? nm : cy.nm;
-        cy.sum = pr ? sum : cy.sum;
+        ssum = pr ? sum : ssum;
         // affine right-hand side and barrier Hessian
         double til = 1.0 / t_l, tiu = 1.0 / t_u;
         stw(L, k, M::TIL + r, til);
@@ -808,6 +820,7 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
             hyy = pr ? fma(wy, jy, hyy) : hyy;
         }
     }
+    cy.sum = cy.sum + ssum;
     double gt[NZ];
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
@@ -967,21 +980,21 @@ __device__ __attribute__((noinline)) void sweep_B0(Lane L, PC<NH> pc, const mpcx
     ret[4 * 64] = cy.sum / (double)m_total;
 }
 
-// Bs: new right-hand side (mode 1 corrector, mode 2 centring), backward
-// substitution with the stored factors
+// Bs: right-hand sides of the corrector (1) and of the centring-only step (2), both
+// substituted backwards with the stored factors in the same pass over the data
 template <int NH, int KIND>
-DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int mode, double sigma_mu,
-                  double *pn)
+DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu,
+                  double *pn1, double *pn2)
 {
     typedef Map<NH> M;
-    double x[NX], u[NU], v[NZ], dva[NZ], gt[NZ];
+    double x[NX], u[NU], v[NZ], dva[NZ], gt1[NZ], gt2[NZ];
     double ll[M::R], lu[M::R], tl[M::R], tu[M::R], til_[M::R], tiu_[M::R];
     load_xu<NH, KIND>(L, k, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
         v[j] = ldw(L, k, M::V + j);
         dva[j] = ldw(L, k, M::DVA + j);
-        gt[j] = ldw(L, k, M::RG + j);
+        gt1[j] = ldw(L, k, M::RG + j);
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
@@ -1010,6 +1023,8 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, in
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
+    for (int j = 0; j < NZ; ++j) gt2[j] = gt1[j];
+#pragma unroll
     for (int r = 0; r < M::R; ++r) {
         if (!row_present<KIND>(r)) continue;
         const bool pr = (r < 9) || (r - 9 < L.nobs);
@@ -1022,76 +1037,95 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, in
         double rdu = (jv - dup) + tu[r];
         double til = til_[r], tiu = tiu_[r];
         double jda = jdot(r, jx, jy, dva);
-        double rml, rmu;
-        row_rm(mode, sigma_mu, jda, ll[r], lu[r], tl[r], tu[r], til, tiu, rdl, rdu, rml, rmu);
-        double ql = fma(-ll[r], rdl, rml) * til;
-        double qu = fma(-lu[r], rdu, rmu) * tiu;
-        double q = ql - qu;
-        if (r < ROW_G0) gt[r] = gt[r] + q;
+        // complementarity targets: corrector and centring-only
+        const double ml = ll[r] * tl[r], mu_ = lu[r] * tu[r];
+        const double dtla = jda - rdl, dtua = -jda - rdu;
+        const double dlla = -(fma(ll[r], dtla, ml) * til);
+        const double dlua = -(fma(lu[r], dtua, mu_) * tiu);
+        const double rml1 = fma(dtla, dlla, ml) - sigma_mu, rmu1 = fma(dtua, dlua, mu_) - sigma_mu;
+        const double rml2 = ml - sigma_mu, rmu2 = mu_ - sigma_mu;
+        const double q1 = fma(-ll[r], rdl, rml1) * til - fma(-lu[r], rdu, rmu1) * tiu;
+        const double q2 = fma(-ll[r], rdl, rml2) * til - fma(-lu[r], rdu, rmu2) * tiu;
+        if (r < ROW_G0) { gt1[r] = gt1[r] + q1; gt2[r] = gt2[r] + q2; }
         else {
-            gt[2] = pr ? fma(jx, q, gt[2]) : gt[2];
-            gt[3] = pr ? fma(jy, q, gt[3]) : gt[3];
+            gt1[2] = pr ? fma(jx, q1, gt1[2]) : gt1[2];
+            gt1[3] = pr ? fma(jy, q1, gt1[3]) : gt1[3];
+            gt2[2] = pr ? fma(jx, q2, gt2[2]) : gt2[2];
+            gt2[3] = pr ? fma(jy, q2, gt2[3]) : gt2[3];
         }
     }
     if (KIND == LAST) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) pn[i] = gt[NU + i];
+        for (int i = 0; i < NX; ++i) { pn1[i] = gt1[NU + i]; pn2[i] = gt2[NU + i]; }
     } else {
-        double w[NX], m[NZ];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) w[i] = pn[i] + prb[i];
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            double *pn = sidx ? pn2 : pn1;
+            double *gt = sidx ? gt2 : gt1;
+            double w[NX], m[NZ];
 #pragma unroll
-        for (int j = 0; j < NZ; ++j) m[j] = gt[j];
-        add_BAt(L, ab, w, m);
-        double y0 = m[0];
-        double y1 = fma(-l10, y0, m[1]);
-        double z0 = y0 * d0, z1 = y1 * d1;
-        double s0 = fma(-l10, z1, z0);
-        stw(L, k, M::KV + 0, -s0);
-        stw(L, k, M::KV + 1, -z1);
+            for (int i = 0; i < NX; ++i) w[i] = pn[i] + prb[i];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) pn[i] = fma(k1[i], m[1], fma(k0[i], m[0], m[NU + i]));
+            for (int j = 0; j < NZ; ++j) m[j] = gt[j];
+            add_BAt(L, ab, w, m);
+            double y0 = m[0];
+            double y1 = fma(-l10, y0, m[1]);
+            double z0 = y0 * d0, z1 = y1 * d1;
+            double s0 = fma(-l10, z1, z0);
+            stw(L, k, (sidx ? M::KV2 : M::KV) + 0, -s0);
+            stw(L, k, (sidx ? M::KV2 : M::KV) + 1, -z1);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) pn[i] = fma(k1[i], m[1], fma(k0[i], m[0], m[NU + i]));
+        }
     }
     if (KIND != FIRST) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) stw(L, k, M::PV + i, pn[i]);
+        for (int i = 0; i < NX; ++i) { stw(L, k, M::PV + i, pn1[i]); stw(L, k, M::PV2 + i, pn2[i]); }
     }
 }
 
 template <int NH>
-__device__ __attribute__((noinline)) void sweep_Bs(Lane L, PC<NH> pc, const mpcx_opts *op, int mode, double sigma_mu)
+__device__ __attribute__((noinline)) void sweep_Bs(Lane L, PC<NH> pc, const mpcx_opts *op, double sigma_mu)
 {
     const mpcx_opts &o = *op;
     const int N = L.N;
-    double pn[NX];
+    double pn1[NX], pn2[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) pn[i] = 0.0;
-    stage_Bs<NH, LAST>(L, o, pc, N, mode, sigma_mu, pn);
-    for (int k = N - 1; k >= 1; --k) stage_Bs<NH, MID>(L, o, pc, k, mode, sigma_mu, pn);
-    stage_Bs<NH, FIRST>(L, o, pc, 0, mode, sigma_mu, pn);
+    for (int i = 0; i < NX; ++i) { pn1[i] = 0.0; pn2[i] = 0.0; }
+    stage_Bs<NH, LAST>(L, o, pc, N, sigma_mu, pn1, pn2);
+    for (int k = N - 1; k >= 1; --k) stage_Bs<NH, MID>(L, o, pc, k, sigma_mu, pn1, pn2);
+    stage_Bs<NH, FIRST>(L, o, pc, 0, sigma_mu, pn1, pn2);
 }
 
 // ---------------------------------------------------------------------------
-// forward sweeps.  AFFINE: stores the predictor step (DVA), returns its longest
-// feasible length and the centring sums.  Otherwise (mode 1 or 2 per lane):
-// stores the step (DV, DPI) and returns its longest feasible length.
+// forward sweeps.  NS = 1: the affine (predictor) step: stores it (DVA), returns
+// its longest feasible length and the centring sums.  NS = 2: the corrector step
+// and the centring-only step side by side: stores both (DV, DPI and DV2, DPI2)
+// and returns both lengths.
 // ---------------------------------------------------------------------------
 // the longest feasible step is num/den: the smallest ratio met so far, kept as a pair and
 // compared by cross multiplication so that a sweep needs one division only
-struct FAcc { double num, den, s1, s2; };
+struct FAcc { double num[2], den[2], s1, s2; };
 
-template <int NH, int KIND, bool AFFINE>
-DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int mode, double sigma_mu,
-                 double *dx, FAcc &a)
+DEV void ratio_min(double val, double step, double &num, double &den)
+{
+    const bool c = (step < 0.0) && (val * den < num * (-step));
+    num = c ? val : num;
+    den = c ? -step : den;
+}
+
+template <int NH, int KIND, int NS>
+DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu,
+                 double (*dx)[NX], FAcc &a)
 {
     typedef Map<NH> M;
-    double x[NX], u[NU], v[NZ], dva[NZ], dvk[NZ], dxn[NX];
+    double x[NX], u[NU], v[NZ], dva[NZ], dvk[NS][NZ], dxn[NS][NX];
     double ll[M::R], lu[M::R], tl[M::R], tu[M::R], til_[M::R], tiu_[M::R];
     load_xu<NH, KIND>(L, k, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
         v[j] = ldw(L, k, M::V + j);
-        dva[j] = AFFINE ? 0.0 : ldw(L, k, M::DVA + j);
+        dva[j] = (NS == 1) ? 0.0 : ldw(L, k, M::DVA + j);
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
@@ -1105,7 +1139,7 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int
         tiu_[r] = ldw(L, k, M::TIU + r);
     }
     AB ab = {};
-    double rb[NX], kv[NU], kg[NU][NX], pv[NX], Pk[15];
+    double rb[NX], kv[NS][NU], kg[NU][NX], pv[NS][NX], Pk[15];
     if (KIND != LAST) {
         load_ab<NH>(L, k, ab);
 #pragma unroll
@@ -1114,41 +1148,50 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int
             kg[0][i] = ldw(L, k, M::K + i);
             kg[1][i] = ldw(L, k, M::K + NX + i);
         }
-        kv[0] = ldw(L, k, M::KV + 0);
-        kv[1] = ldw(L, k, M::KV + 1);
-    }
-    if (!AFFINE && KIND != FIRST) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) pv[i] = ldw(L, k, M::PV + i);
+        for (int q = 0; q < NS; ++q) {
+            kv[q][0] = ldw(L, k, M::KV + q * M::SOL2 + 0);
+            kv[q][1] = ldw(L, k, M::KV + q * M::SOL2 + 1);
+        }
+    }
+    if (NS == 2 && KIND != FIRST) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+            for (int i = 0; i < NX; ++i) pv[q][i] = ldw(L, k, M::PV + q * M::SOL2 + i);
 #pragma unroll
         for (int i = 0; i < 15; ++i) Pk[i] = ldw(L, k, M::P + i);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { dvk[NU + i] = dx[i]; dxn[i] = 0.0; }
-    dvk[0] = dvk[1] = 0.0;
-    if (!AFFINE && KIND != FIRST) {
-        // multiplier step of the dynamics equation that defines x_k
+    for (int q = 0; q < NS; ++q) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            double acc = pv[i];
+        for (int i = 0; i < NX; ++i) { dvk[q][NU + i] = dx[q][i]; dxn[q][i] = 0.0; }
+        dvk[q][0] = dvk[q][1] = 0.0;
+        if (NS == 2 && KIND != FIRST) {
+            // multiplier step of the dynamics equation that defines x_k
 #pragma unroll
-            for (int j = 0; j < NX; ++j) acc = fma(psym(Pk, i, j), dx[j], acc);
-            stw(L, k, M::DPI + i, acc);
+            for (int i = 0; i < NX; ++i) {
+                double acc = pv[q][i];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) acc = fma(psym(Pk, i, j), dx[q][j], acc);
+                stw(L, k, M::DPI + q * M::SOL2 + i, acc);
+            }
         }
-    }
-    if (KIND != LAST) {
+        if (KIND != LAST) {
 #pragma unroll
-        for (int c = 0; c < NU; ++c) {
-            double acc = kv[c];
+            for (int c = 0; c < NU; ++c) {
+                double acc = kv[q][c];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) acc = fma(kg[c][i], dx[i], acc);
-            dvk[c] = acc;
+                for (int i = 0; i < NX; ++i) acc = fma(kg[c][i], dx[q][i], acc);
+                dvk[q][c] = acc;
+            }
+            mul_AB(L, ab, dx[q], dvk[q], rb, dxn[q]);
         }
-        mul_AB(L, ab, dx, dvk, rb, dxn);
-    }
 #pragma unroll
-    for (int j = 0; j < NZ; ++j) stw(L, k, (AFFINE ? M::DVA : M::DV) + j, dvk[j]);
+        for (int j = 0; j < NZ; ++j) stw(L, k, (NS == 1 ? M::DVA : M::DV + q * M::SOL2) + j, dvk[q][j]);
+    }
+    double s1k = 0.0, s2k = 0.0;
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
         if (!row_present<KIND>(r)) continue;
@@ -1161,52 +1204,72 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, int
         double rdl = (dlo - jv) + tl[r];
         double rdu = (jv - dup) + tu[r];
         double til = til_[r], tiu = tiu_[r];
-        double jda = AFFINE ? 0.0 : jdot(r, jx, jy, dva);
-        double rml, rmu;
-        if (AFFINE) { rml = ll[r] * tl[r]; rmu = lu[r] * tu[r]; }
-        else row_rm(mode, sigma_mu, jda, ll[r], lu[r], tl[r], tu[r], til, tiu, rdl, rdu, rml, rmu);
-        double jd = jdot(r, jx, jy, dvk);
-        double dtl = jd - rdl;
-        double dtu = -jd - rdu;
-        double dll = -(fma(ll[r], dtl, rml) * til);
-        double dlu = -(fma(lu[r], dtu, rmu) * tiu);
-        double num = a.num, den = a.den;
-        { const bool c = (dll < 0.0) && (ll[r] * den < num * (-dll)); num = c ? ll[r] : num; den = c ? -dll : den; }
-        { const bool c = (dtl < 0.0) && (tl[r] * den < num * (-dtl)); num = c ? tl[r] : num; den = c ? -dtl : den; }
-        { const bool c = (dlu < 0.0) && (lu[r] * den < num * (-dlu)); num = c ? lu[r] : num; den = c ? -dlu : den; }
-        { const bool c = (dtu < 0.0) && (tu[r] * den < num * (-dtu)); num = c ? tu[r] : num; den = c ? -dtu : den; }
-        a.num = pr ? num : a.num;
-        a.den = pr ? den : a.den;
-        if (AFFINE) {
-            double s1 = a.s1, s2 = a.s2;
-            s1 = fma(ll[r], dtl, s1);
-            s1 = fma(tl[r], dll, s1);
-            s1 = fma(lu[r], dtu, s1);
-            s1 = fma(tu[r], dlu, s1);
-            s2 = fma(dtl, dll, s2);
-            s2 = fma(dtu, dlu, s2);
-            a.s1 = pr ? s1 : a.s1;
-            a.s2 = pr ? s2 : a.s2;
+        const double ml = ll[r] * tl[r], mu_ = lu[r] * tu[r];
+        double rml[NS], rmu[NS];
+        if (NS == 1) { rml[0] = ml; rmu[0] = mu_; }
+        else {
+            double jda = jdot(r, jx, jy, dva);
+            const double dtla = jda - rdl, dtua = -jda - rdu;
+            const double dlla = -(fma(ll[r], dtla, ml) * til);
+            const double dlua = -(fma(lu[r], dtua, mu_) * tiu);
+            rml[0] = fma(dtla, dlla, ml) - sigma_mu;
+            rmu[0] = fma(dtua, dlua, mu_) - sigma_mu;
+            rml[NS - 1] = ml - sigma_mu;
+            rmu[NS - 1] = mu_ - sigma_mu;
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            double jd = jdot(r, jx, jy, dvk[q]);
+            double dtl = jd - rdl;
+            double dtu = -jd - rdu;
+            double dll = -(fma(ll[r], dtl, rml[q]) * til);
+            double dlu = -(fma(lu[r], dtu, rmu[q]) * tiu);
+            double num = a.num[q], den = a.den[q];
+            ratio_min(ll[r], dll, num, den);
+            ratio_min(tl[r], dtl, num, den);
+            ratio_min(lu[r], dlu, num, den);
+            ratio_min(tu[r], dtu, num, den);
+            a.num[q] = pr ? num : a.num[q];
+            a.den[q] = pr ? den : a.den[q];
+            if (NS == 1) {
+                double s1 = s1k, s2 = s2k;
+                s1 = fma(ll[r], dtl, s1);
+                s1 = fma(tl[r], dll, s1);
+                s1 = fma(lu[r], dtu, s1);
+                s1 = fma(tu[r], dlu, s1);
+                s2 = fma(dtl, dll, s2);
+                s2 = fma(dtu, dlu, s2);
+                s1k = pr ? s1 : s1k;
+                s2k = pr ? s2 : s2k;
+            }
         }
     }
+    if (NS == 1) { a.s1 = a.s1 + s1k; a.s2 = a.s2 + s2k; }
 #pragma unroll
-    for (int i = 0; i < NX; ++i) dx[i] = dxn[i];
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[q][i] = dxn[q][i];
 }
 
-template <int NH, bool AFFINE>
-__device__ __attribute__((noinline)) double sweep_F(Lane L, PC<NH> pc, const mpcx_opts *op, int mode, double sigma_mu, ldouble *ret)
+// NS = 1: returns the affine step length, ret[0], ret[1] = S1, S2.
+// NS = 2: returns the corrector step length, ret[0] = the centring-only one.
+template <int NH, int NS>
+__device__ __attribute__((noinline)) double sweep_F(Lane L, PC<NH> pc, const mpcx_opts *op, double sigma_mu, ldouble *ret)
 {
     const mpcx_opts &o = *op;
     const int N = L.N;
-    FAcc a = {1.0, 1.0, 0.0, 0.0};
-    double dx[NX];
+    FAcc a = {{1.0, 1.0}, {1.0, 1.0}, 0.0, 0.0};
+    double dx[NS][NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) dx[i] = 0.0;
-    stage_F<NH, FIRST, AFFINE>(L, o, pc, 0, mode, sigma_mu, dx, a);
-    for (int k = 1; k < N; ++k) stage_F<NH, MID, AFFINE>(L, o, pc, k, mode, sigma_mu, dx, a);
-    stage_F<NH, LAST, AFFINE>(L, o, pc, N, mode, sigma_mu, dx, a);
-    if (AFFINE) { ret[0 * 64] = a.s1; ret[1 * 64] = a.s2; }
-    return a.num / a.den;
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[q][i] = 0.0;
+    stage_F<NH, FIRST, NS>(L, o, pc, 0, sigma_mu, dx, a);
+    for (int k = 1; k < N; ++k) stage_F<NH, MID, NS>(L, o, pc, k, sigma_mu, dx, a);
+    stage_F<NH, LAST, NS>(L, o, pc, N, sigma_mu, dx, a);
+    if (NS == 1) { ret[0 * 64] = a.s1; ret[1 * 64] = a.s2; }
+    else ret[0 * 64] = a.num[1] / a.den[1];
+    return a.num[0] / a.den[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -1242,10 +1305,16 @@ __device__ unsigned long long g_stamps[2048][N_STAMP];
 enum LaneState {
     LS_FETCH = 0,   // needs a problem
     LS_LIN = 1,     // needs sweep L (new SQP iteration)
-    LS_FACT = 2,    // interior point: needs B0 + F0 (new iteration)
-    LS_SOLVE = 3,   // interior point: needs Bs + F with `mode`
+    LS_QP = 2,      // inside the interior point: one iteration per tick
+    LS_OUT = 3,     // problem ended, results not written yet
     LS_DONE = 4     // no problems left
 };
+
+// Write-out, fetch and sweep L ("service") run with few lanes each, so they are held
+// back until this many lanes wait for them (or no lane has interior-point work).
+#ifndef MPCX_SERVICE_MIN
+#define MPCX_SERVICE_MIN 8
+#endif
 
 template <int NH>
 __global__ void __launch_bounds__(64)
@@ -1275,203 +1344,178 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     L.h = L.hh = L.h6 = L.hB = L.invL = 0.0;
 
     int state = LS_FETCH;
-    int status = MPCX_MAXITER, sqp_it = 0, qp_it = 0, qp_total = 0, mode = 1, m_total = 0;
+    int status = MPCX_MAXITER, sqp_it = 0, qp_it = 0, qp_total = 0, m_total = 0;
     bool first = true;
     double res[4] = {0.0, 0.0, 0.0, 0.0};
-    double cost = 0.0, a_aff = 0.0, sigma_mu = 0.0;
-    QpRes R = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double cost = 0.0;
     Step sp;
     sp.have = false; sp.mode = 0; sp.sigma_mu = 0.0; sp.alpha = 0.0;
 
     for (;;) {
         STAMP_BEGIN();
-        const bool st_a = (state == LS_FETCH);
-        // ---- A: take a problem, write the initial iterate -------------------------------
-        if (state == LS_FETCH) {
-            unsigned b = (unsigned)atomicAdd(counter, 1);
-            if (b >= B) {
-                state = LS_DONE;
-            } else {
-                L.b = b;
-                int nobs = in.n_obs ? in.n_obs[b] : 0;
-                if (nobs < 0 || nobs > NH) {     // the host validates; stay memory safe regardless
-                    out.status[b] = MPCX_NAN;
-                    out.sqp_iter[b] = 0;
-                    out.qp_iter[b] = 0;
-                } else {
-                    L.nobs = nobs;
-                    L.h = ldp(L, MPCX_F_H);
-                    L.hh = 0.5 * L.h;
-                    L.h6 = L.h / 6.0;
-                    L.hB = L.h6 * 6.0;
-                    L.invL = 1.0 / ldp(L, MPCX_F_L);
-                    fill_pc<NH>(L, o, pc);
-                    // row sides: stage 0 has the 2 input rows, stages 1..N-1 all rows, stage N 7 rows
-                    m_total = 2 * (NU + (N - 1) * (9 + nobs) + 7);
-                    for (int k = 0; k <= N; ++k) {
+        // ---- service: results out, next problem in, new SQP iteration ---------------------
+        const bool wants = (state == LS_OUT) || (state == LS_FETCH) || (state == LS_LIN);
+        const int n_wants = __popcll(__ballot(wants));
+        const int n_qp = __popcll(__ballot(state == LS_QP));
+        if (n_wants >= MPCX_SERVICE_MIN || n_qp == 0) {
+            const bool st_e = (state == LS_OUT);
+            if (state == LS_OUT) {
+                const size_t b = L.b;
+                for (int k = 0; k <= N; ++k) {
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) {
-                            stw(L, k, M::X + i, in.xguess[((size_t)k * NX + i) * L.B + b]);
-                            stw(L, k, M::QPI + i, 0.0);
-                        }
-                        stw(L, k, M::U + 0, 0.0);
-                        stw(L, k, M::U + 1, 0.0);
-#pragma unroll
-                        for (int r = 0; r < M::R; ++r) {
-                            stw(L, k, M::LAML + r, 0.0);
-                            stw(L, k, M::LAMU + r, 0.0);
-                        }
+                    for (int i = 0; i < NX; ++i)
+                        out.X[(b * (size_t)(N + 1) + k) * NX + i] = ldw(L, k, M::X + i);
+                    if (k < N) {
+                        out.U[(b * (size_t)N + k) * NU + 0] = ldw(L, k, M::U + 0);
+                        out.U[(b * (size_t)N + k) * NU + 1] = ldw(L, k, M::U + 1);
                     }
-                    status = MPCX_MAXITER;
-                    sqp_it = 0;
-                    qp_total = 0;
-                    first = true;
-                    state = LS_LIN;
+                }
+                out.status[b] = status;
+                out.sqp_iter[b] = sqp_it;
+                out.qp_iter[b] = qp_total;
+                out.cost[b] = cost;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) out.res[(size_t)i * L.B + b] = res[i];
+                state = LS_FETCH;
+            }
+            STAMP(8, st_e);
+            const bool st_a = (state == LS_FETCH);
+            if (state == LS_FETCH) {
+                unsigned b = (unsigned)atomicAdd(counter, 1);
+                if (b >= B) {
+                    state = LS_DONE;
+                } else {
+                    L.b = b;
+                    int nobs = in.n_obs ? in.n_obs[b] : 0;
+                    if (nobs < 0 || nobs > NH) {     // the host validates; stay memory safe regardless
+                        out.status[b] = MPCX_NAN;
+                        out.sqp_iter[b] = 0;
+                        out.qp_iter[b] = 0;
+                    } else {
+                        L.nobs = nobs;
+                        L.h = ldp(L, MPCX_F_H);
+                        L.hh = 0.5 * L.h;
+                        L.h6 = L.h / 6.0;
+                        L.hB = L.h6 * 6.0;
+                        L.invL = 1.0 / ldp(L, MPCX_F_L);
+                        fill_pc<NH>(L, o, pc);
+                        // row sides: stage 0 has the 2 input rows, stages 1..N-1 all rows, stage N 7 rows
+                        m_total = 2 * (NU + (N - 1) * (9 + nobs) + 7);
+                        for (int k = 0; k <= N; ++k) {
+#pragma unroll
+                            for (int i = 0; i < NX; ++i) {
+                                stw(L, k, M::X + i, in.xguess[((size_t)k * NX + i) * L.B + b]);
+                                stw(L, k, M::QPI + i, 0.0);
+                            }
+                            stw(L, k, M::U + 0, 0.0);
+                            stw(L, k, M::U + 1, 0.0);
+#pragma unroll
+                            for (int r = 0; r < M::R; ++r) {
+                                stw(L, k, M::LAML + r, 0.0);
+                                stw(L, k, M::LAMU + r, 0.0);
+                            }
+                        }
+                        status = MPCX_MAXITER;
+                        sqp_it = 0;
+                        qp_total = 0;
+                        first = true;
+                        state = LS_LIN;
+                    }
                 }
             }
+            STAMP(0, st_a);
+            const bool st_b = (state == LS_LIN);
+            if (state == LS_LIN) {
+                if (o.rti && !first) {
+                    // real-time iteration: apply the one step, report the new objective
+                    sweep_L<NH>(L, pc, op, false, ret);
+                    cost = ret[4 * 64];
+                    status = MPCX_SUCCESS;
+                    state = LS_OUT;
+                } else {
+                    sweep_L<NH>(L, pc, op, first, ret);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) res[i] = ret[i * 64];
+                    cost = ret[4 * 64];
+                    first = false;
+                    state = LS_OUT;
+                    if (!(finite_d(res[0]) && finite_d(res[1]) && finite_d(res[2]) && finite_d(res[3]))) {
+                        status = MPCX_NAN;
+                    } else if (!o.rti && res[0] < o.tol_stat && res[1] < o.tol_eq && res[2] < o.tol_ineq &&
+                               res[3] < o.tol_comp) {
+                        status = MPCX_SUCCESS;
+                    } else if (sqp_it >= o.max_sqp_iter) {
+                        status = MPCX_MAXITER;
+                    } else {
+                        state = LS_QP;
+                        sp.have = false;
+                        qp_it = 0;
+                    }
+                }
+            }
+            STAMP(1, st_b);
         }
         if (!__any(state != LS_DONE)) break;
-        STAMP(0, st_a);
 
-        // ---- B: SQP level -----------------------------------------------------------------
-        bool finished = false;
-        const bool st_b = (state == LS_LIN);
-        if (state == LS_LIN) {
-            if (o.rti && !first) {
-                // real-time iteration: apply the one step, report the new objective
-                sweep_L<NH>(L, pc, op, false, ret);
-                cost = ret[4 * 64];
-                status = MPCX_SUCCESS;
-                finished = true;
-            } else {
-                sweep_L<NH>(L, pc, op, first, ret);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) res[i] = ret[i * 64];
-                cost = ret[4 * 64];
-                first = false;
-                if (!(finite_d(res[0]) && finite_d(res[1]) && finite_d(res[2]) && finite_d(res[3]))) {
-                    status = MPCX_NAN;
-                    finished = true;
-                } else if (!o.rti && res[0] < o.tol_stat && res[1] < o.tol_eq && res[2] < o.tol_ineq &&
-                           res[3] < o.tol_comp) {
-                    status = MPCX_SUCCESS;
-                    finished = true;
-                } else if (sqp_it >= o.max_sqp_iter) {
-                    status = MPCX_MAXITER;
-                    finished = true;
-                } else {
-                    state = LS_FACT;
-                    sp.have = false;
-                    qp_it = 0;
-                }
-            }
-        }
-
-        STAMP(1, st_b);
-        // ---- C: interior point, factorisation and predictor --------------------------------
-        const bool st_c = (state == LS_FACT);
-        if (state == LS_FACT) {
+        // ---- one interior-point iteration ---------------------------------------------------
+        const bool st_c = (state == LS_QP);
+        bool iterate = false;
+        if (state == LS_QP) {
             sweep_B0<NH>(L, pc, op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, m_total, ret);
-            R.g = ret[0 * 64]; R.b = ret[1 * 64]; R.d = ret[2 * 64]; R.m = ret[3 * 64]; R.mu = ret[4 * 64];
-        }
-        STAMP(2, st_c);
-        if (state == LS_FACT) {
+            const double Rg = ret[0 * 64], Rb = ret[1 * 64], Rd = ret[2 * 64], Rm = ret[3 * 64];
             int qs = -1;     // HPIPM-style: 0 solved, 1 iteration limit, 3 NaN
-            if (!(finite_d(R.g) && finite_d(R.b) && finite_d(R.d) && finite_d(R.m))) qs = 3;
-            else if (R.g < o.qp_tol_stat && R.b < o.qp_tol_eq && R.d < o.qp_tol_ineq && R.m < o.qp_tol_comp) qs = 0;
+            if (!(finite_d(Rg) && finite_d(Rb) && finite_d(Rd) && finite_d(Rm))) qs = 3;
+            else if (Rg < o.qp_tol_stat && Rb < o.qp_tol_eq && Rd < o.qp_tol_ineq && Rm < o.qp_tol_comp) qs = 0;
             else if (qp_it >= o.max_qp_iter) qs = 1;
             if (qs >= 0) {
                 qp_total += qp_it;
                 ++sqp_it;
-                if (qs == 3) {
-                    status = MPCX_QP_FAILURE;
-                    finished = true;
-                } else {
-                    state = LS_LIN;          // the next sweep L applies the step
-                }
+                if (qs == 3) { status = MPCX_QP_FAILURE; state = LS_OUT; }
+                else state = LS_LIN;          // the next sweep L applies the step
             } else {
-                a_aff = sweep_F<NH, true>(L, pc, op, 0, 0.0, ret);
-                const double S1 = ret[0 * 64], S2 = ret[1 * 64];
-                double S0 = R.mu * (double)m_total;
-                double mu_aff = fma(a_aff, fma(a_aff, S2, S1), S0) / (double)m_total;
-                if (mu_aff < 0.0) mu_aff = 0.0;
-                double ratio = mu_aff / R.mu;
-                double sigma = ratio * ratio * ratio;
-                sigma_mu = sigma * R.mu;
-                mode = 1;
-                state = LS_SOLVE;
+                iterate = true;
             }
         }
-
-        STAMP(3, st_c);
-        // ---- D: corrector; centring-only re-solve where the corrector shortened the step ----
-        // Lanes that need the re-solve run it in a second pass right away when they are at
-        // least a third of the solving lanes; otherwise they keep state LS_SOLVE (mode 2),
-        // sit out the next tick's C and join its D.
-        {
-            bool run = (state == LS_SOLVE);
-            for (int pass = 0; pass < 2; ++pass) {
-                if (!__any(run)) break;
-                double alpha = 0.0;
-                bool again = false;
-                if (run) sweep_Bs<NH>(L, pc, op, mode, sigma_mu);
-                STAMP(4 + 2 * pass, run);
-                if (run) {
-                    alpha = sweep_F<NH, false>(L, pc, op, mode, sigma_mu, ret);
-                    again = (mode == 1) && o.cond_pred_corr && (alpha < a_aff);
-                    if (!again) {
-                        ++qp_it;
-                        if (!(alpha > o.alpha_min)) {      // minimum step or NaN
-                            qp_total += qp_it;
-                            ++sqp_it;
-                            status = MPCX_QP_FAILURE;
-                            finished = true;
-                            state = LS_FETCH;
-                        } else {
-                            sp.have = true;
-                            sp.mode = mode;
-                            sp.sigma_mu = sigma_mu;
-                            sp.alpha = alpha * fma(alpha, 0.9999999, (1.0 - alpha) * 0.99);
-                            state = LS_FACT;
-                        }
-                    } else {
-                        mode = 2;
-                    }
-                }
-                STAMP(5 + 2 * pass, run);
-                const int n_again = __popcll(__ballot(again));
-                const int n_run = __popcll(__ballot(run));
-                const bool immediate = (3 * n_again >= n_run);
-                run = again && immediate;
+        STAMP(2, st_c);
+        double a_aff = 0.0, sigma_mu = 0.0;
+        if (iterate) {
+            const double mu = ret[4 * 64];
+            a_aff = sweep_F<NH, 1>(L, pc, op, 0.0, ret);
+            const double S1 = ret[0 * 64], S2 = ret[1 * 64];
+            double S0 = mu * (double)m_total;
+            double mu_aff = fma(a_aff, fma(a_aff, S2, S1), S0) / (double)m_total;
+            if (mu_aff < 0.0) mu_aff = 0.0;
+            double ratio = mu_aff / mu;
+            double sigma = ratio * ratio * ratio;
+            sigma_mu = sigma * mu;
+        }
+        STAMP(3, iterate);
+        if (iterate) sweep_Bs<NH>(L, pc, op, sigma_mu);
+        STAMP(4, iterate);
+        if (iterate) {
+            // the corrector step, or the centring-only one where the corrector is the shorter
+            const double alpha1 = sweep_F<NH, 2>(L, pc, op, sigma_mu, ret);
+            const double alpha2 = ret[0 * 64];
+            const bool use2 = o.cond_pred_corr && (alpha1 < a_aff);
+            const double alpha = use2 ? alpha2 : alpha1;
+            ++qp_it;
+            if (!(alpha > o.alpha_min)) {      // minimum step or NaN
+                qp_total += qp_it;
+                ++sqp_it;
+                status = MPCX_QP_FAILURE;
+                state = LS_OUT;
+            } else {
+                sp.have = true;
+                sp.mode = use2 ? 2 : 1;
+                sp.sigma_mu = sigma_mu;
+                sp.alpha = alpha * fma(alpha, 0.9999999, (1.0 - alpha) * 0.99);
             }
         }
-
-        // ---- E: results of finished problems ------------------------------------------------
-        if (finished) {
-            const size_t b = L.b;
-            for (int k = 0; k <= N; ++k) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i)
-                    out.X[(b * (size_t)(N + 1) + k) * NX + i] = ldw(L, k, M::X + i);
-                if (k < N) {
-                    out.U[(b * (size_t)N + k) * NU + 0] = ldw(L, k, M::U + 0);
-                    out.U[(b * (size_t)N + k) * NU + 1] = ldw(L, k, M::U + 1);
-                }
-            }
-            out.status[b] = status;
-            out.sqp_iter[b] = sqp_it;
-            out.qp_iter[b] = qp_total;
-            out.cost[b] = cost;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) out.res[(size_t)i * L.B + b] = res[i];
-            state = LS_FETCH;
-        }
-        STAMP(8, finished);
+        STAMP(5, iterate);
         STAMP(9, state != LS_DONE);      // lanes-sum / 64 = ticks; lanes that still have work
         STAMP(10, true);
     }
 }
-
 
 // sin/cos as the solver computes them, for the arithmetic parity tests
 __global__ void mpcx_probe_kernel(const double *xin, int n, double *s, double *c)

@@ -410,6 +410,7 @@ static void qp_residuals(const problem *pb, stage *st, int m_total, qp_res *R)
         }
         if (k > 0)
             for (int i = 0; i < NX; ++i) s->rg[NU + i] = s->rg[NU + i] - s->qpi[i];
+        real ssum = 0.0;     /* complementarity products of this stage, then added to the total */
         for (int r = s->r0; r < s->r1; ++r) {
             real jv = row_dot(s, r, s->v);
             real dl = s->lam_u[r] - s->lam_l[r];
@@ -425,9 +426,10 @@ static void qp_residuals(const problem *pb, stage *st, int m_total, qp_res *R)
             real ml = s->lam_l[r] * s->t_l[r], mu_ = s->lam_u[r] * s->t_u[r];
             nm = rmax(nm, rabs(ml));
             nm = rmax(nm, rabs(mu_));
-            sum = sum + ml;
-            sum = sum + mu_;
+            ssum = ssum + ml;
+            ssum = ssum + mu_;
         }
+        sum = sum + ssum;
         int j0 = (k == N) ? NU : 0, j1 = (k == 0) ? NU : NZ;
         for (int j = j0; j < j1; ++j) ng = rmax(ng, rabs(s->rg[j]));
         if (k < N) {
@@ -675,6 +677,7 @@ static real qp_step_length(const problem *pb, stage *st, int mode, real sigma_mu
     real num = 1.0, den = 1.0, s1 = 0.0, s2 = 0.0;
     for (int k = 0; k <= N; ++k) {
         stage *s = &st[k];
+        real s1k = 0.0, s2k = 0.0;    /* sums of this stage, then added to the totals */
         for (int r = s->r0; r < s->r1; ++r) {
             real til = (real)1.0 / s->t_l[r], tiu = (real)1.0 / s->t_u[r];
             real rml = s->lam_l[r] * s->t_l[r], rmu = s->lam_u[r] * s->t_u[r];
@@ -699,13 +702,15 @@ static real qp_step_length(const problem *pb, stage *st, int mode, real sigma_mu
             if (dtl < (real)0.0 && s->t_l[r] * den < num * (-dtl)) { num = s->t_l[r]; den = -dtl; }
             if (dlu < (real)0.0 && s->lam_u[r] * den < num * (-dlu)) { num = s->lam_u[r]; den = -dlu; }
             if (dtu < (real)0.0 && s->t_u[r] * den < num * (-dtu)) { num = s->t_u[r]; den = -dtu; }
-            s1 = rfma(s->lam_l[r], dtl, s1);
-            s1 = rfma(s->t_l[r], dll, s1);
-            s1 = rfma(s->lam_u[r], dtu, s1);
-            s1 = rfma(s->t_u[r], dlu, s1);
-            s2 = rfma(dtl, dll, s2);
-            s2 = rfma(dtu, dlu, s2);
+            s1k = rfma(s->lam_l[r], dtl, s1k);
+            s1k = rfma(s->t_l[r], dll, s1k);
+            s1k = rfma(s->lam_u[r], dtu, s1k);
+            s1k = rfma(s->t_u[r], dlu, s1k);
+            s2k = rfma(dtl, dll, s2k);
+            s2k = rfma(dtu, dlu, s2k);
         }
+        s1 = s1 + s1k;
+        s2 = s2 + s2k;
     }
     if (S1) *S1 = s1;
     if (S2) *S2 = s2;

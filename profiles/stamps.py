@@ -27,8 +27,8 @@ NS = 24
 buf = np.zeros((2048, NS), dtype=np.uint64)
 lib.mpcx_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.mpcx_debug_read_stamps(buf.ctypes.data, 1) == 0
-names = ["A fetch+init", "B sweep L", "C sweep B0", "C sweep F0", "D pass0 Bs", "D pass0 F",
-         "D pass1 Bs", "D pass1 F", "E write-out", "busy lanes", "ticks*64"]
+names = ["A fetch+init", "B sweep L", "sweep B0", "sweep F (affine)", "sweep Bs (both rhs)", "sweep F (both steps)",
+         "-", "-", "E write-out", "busy lanes", "ticks*64"]
 cyc = buf[:, 0::2].astype(np.float64)
 cnt = buf[:, 1::2].astype(np.float64)
 used = cyc.sum(1) > 0
