@@ -27,7 +27,7 @@ HBM_PEAK_GBS = 8000.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1_000_000, help="problems per GPU")
     ap.add_argument("--cpu-sample", type=int, default=16384, help="problems timed on the CPU oracle (0 = skip)")

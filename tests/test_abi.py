@@ -1,0 +1,62 @@
+"""The C-ABI library loads and exports every symbol include/mpcx.h declares;
+argument checking works without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from mpc_amd import _lib
+from mpc_amd.synthetic import synthetic_batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "mpcx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpcx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_exports_match_header():
+    lib = _lib.load_library()
+    names = declared_functions()
+    assert {"mpcx_version", "mpcx_last_error", "mpcx_opts_default", "mpcx_device_count",
+            "mpcx_solve_batch", "mpcx_workspace_bytes", "mpcx_solve_batch_device",
+            "mpcx_probe_sincos"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mpcx.h but not exported"
+    assert lib.mpcx_version() == 100
+
+
+def test_struct_layout_and_defaults():
+    o = _lib.default_opts()
+    assert C.sizeof(_lib.MpcxOpts) == 136 and C.sizeof(_lib.MpcxBatch) == 32 and C.sizeof(_lib.MpcxResult) == 56
+    assert (o.max_sqp_iter, o.max_qp_iter, o.tol_stat, o.lm) == (200, 50, 1e-3, 1e-2)   # core_solver.py:246-252
+    assert (o.qp_tol_comp, o.mu0, o.thr0, o.cond_pred_corr, o.rti, o.max_obs) == (1e-3, 10.0, 0.1, 1, 0, -1)
+
+
+def test_oracle_and_library_share_defaults(oracle):
+    a, b = _lib.default_opts(), oracle.default_opts()
+    assert bytes(a) == bytes(b)
+
+
+def test_bad_arguments_and_no_device():
+    lib = _lib.load_library()
+    p = synthetic_batch(8)
+    out = _lib.alloc_result(p.B, p.N)
+    o = _lib.default_opts()
+    b, r = _lib.batch_struct(p), _lib.result_struct(out)
+    assert lib.mpcx_solve_batch(None, C.byref(o), C.byref(r), 0) == -1
+    b.N = 0
+    assert lib.mpcx_solve_batch(C.byref(b), C.byref(o), C.byref(r), 0) == -1
+    assert b"N >= 1" in lib.mpcx_last_error()
+    b.N = p.N
+    o.max_obs = 9
+    assert lib.mpcx_solve_batch(C.byref(b), C.byref(o), C.byref(r), 0) == -1
+    o.max_obs = -1
+    assert lib.mpcx_workspace_bytes(0, 50) == 0 and lib.mpcx_workspace_bytes(64, 50) > 0
+    if lib.mpcx_device_count() == 0:
+        assert lib.mpcx_solve_batch(C.byref(b), C.byref(o), C.byref(r), 0) == -2      # MPCX_E_NODEVICE
+        x = np.zeros(4)
+        assert lib.mpcx_probe_sincos(x.ctypes.data, 4, x.ctypes.data, x.ctypes.data, 0) == -2

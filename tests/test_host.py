@@ -1,0 +1,168 @@
+"""Host-side logic: configuration objects, corridor, initial guess, packing,
+grouping and ordering.  No GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mpc_amd import EgoConfig, SimConfig, corridor_cal, verify_point_in_corridor
+from mpc_amd import batch as bt
+from mpc_amd.core_solver import find_path, find_paths, generate_controls, solve_groups
+from mpc_amd.grid_path_plan import grid_start_states
+from mpc_amd.synthetic import random_start_goal, synthetic_batch
+
+import cases
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = json.load(open(os.path.join(HERE, "golden", "corridor_guess.json")))
+
+
+def test_ego_defaults_and_setters():
+    e = EgoConfig()
+    assert e.L == 2.7 and e.corridor_width == 15.0 and e.obstacles is None and e.verbose is True
+    assert (e.velocity_min, e.velocity_max, e.acceleration_min, e.acceleration_max) == (-3.0, 3.0, -2.0, 2.0)
+    assert (e.steering_min, e.steering_max, e.steering_rate_min, e.steering_rate_max) == (-0.5, 0.5, -0.4, 0.4)
+    assert e.state_start == [-40, 0, 0, 0, 0] and e.state_final == [40, 0, 0, 0, 0]
+    assert (e.weight_acceleration, e.weight_steering_rate) == (100.0, 100.0)
+    assert (e.weight_terminal_position_x, e.weight_terminal_heading, e.weight_terminal_velocity) == (100.0, 100.0, 10.0)
+    src = [1.0, 2.0, np.pi, 0.5, 0.0]
+    e.state_start = src
+    assert e.state_start is not src and src[2] == np.pi          # copied, input untouched
+    assert e.state_start[2] == -np.pi                            # +pi wraps to -pi
+    e.state_final = [0, 0, 3 * np.pi / 2, 0, 0]
+    assert abs(e.state_final[2] + np.pi / 2) < 1e-15
+    with pytest.raises(ValueError):
+        e.state_start = [0, 0, 0]
+    s = SimConfig()
+    assert (s.duration, s.dt) == (30.0, 0.1)
+
+
+def test_horizon_truncation():
+    s = SimConfig()
+    for duration, n in ((30.0, 300), (40, 400), (80, 800), (15.0, 150), (22.0, 220), (5.0, 50), (0.3, 2)):
+        s.duration = duration
+        assert bt.horizon_length(s) == n
+
+
+def test_corridor_fixtures():
+    for c in FIX["corridor"]:
+        got = corridor_cal(tuple(c["a"]), tuple(c["b"]), c["distance"])
+        assert [float(v) for v in got] == c["coeffs"]
+    # hand-checked: horizontal line y = 5, half-width 2
+    c1, a1, b1, c2, a2, b2 = corridor_cal((0, 5), (10, 5), 2.0)
+    assert (c1, b1, b2) == (1.0, -3.0, -7.0) and a1 == 0
+    assert verify_point_in_corridor((5, 5), c1, a1, b1, c2, a2, b2)
+    assert not verify_point_in_corridor((5, 8), c1, a1, b1, c2, a2, b2)
+    with pytest.raises(ValueError):
+        corridor_cal((1, 1), (1, 1), 2.0)
+
+
+def test_initial_guess_fixtures():
+    ego, sim = cases.make_scenario("path_finder")
+    g = bt.initial_guess(ego, 400)
+    for i, row in FIX["guess"]["path_finder"]["rows"].items():
+        assert g[int(i)].tolist() == row
+    assert g[400].tolist() == [float(v) for v in ego.state_final]     # last node is the goal itself
+    assert g[0, 3] == 1.0                                             # speed guess ignores the start speed
+    g = bt.initial_guess(EgoConfig(), 300)
+    for i, row in FIX["guess"]["default"]["rows"].items():
+        assert g[int(i)].tolist() == row
+    # hand check, obstacle branch: the path line is shifted sideways by R - dist + 0.1
+    r = 4.0 + 1.0 + 0.05
+    dist = np.hypot(-9.5 + 7, 9.5 - 12)
+    shift = r - dist + 0.1
+    g0 = bt.initial_guess(ego, 400)[0]
+    assert abs(np.hypot(g0[0] + 20, g0[1] - 20) - np.hypot(shift, 0.6066017177982133)) < 1e-9
+
+
+def test_vectorised_packing_equals_scalar():
+    start, goal = random_start_goal(300, seed=5)
+    start[:, 2] += np.linspace(-7, 7, 300)        # exercise the heading wrap
+    packed_v = bt.pack_arrays(start, goal, 5.0)
+    egos = []
+    for s, g in zip(start, goal):
+        e = EgoConfig()
+        e.state_start = [float(v) for v in s]
+        e.state_final = [float(v) for v in g]
+        egos.append(e)
+    sim = SimConfig()
+    sim.duration = 5.0
+    packed_s = bt.pack_problems(egos, sim)
+    assert packed_v.N == packed_s.N == 50
+    assert np.array_equal(packed_v.pdata, packed_s.pdata)
+    assert np.array_equal(packed_v.xguess, packed_s.xguess)
+    assert np.array_equal(packed_v.n_obs, packed_s.n_obs)
+
+
+def test_pack_fields():
+    ego, sim = cases.make_scenario("path_finder")
+    p = bt.pack_problems([ego], sim)
+    col = p.pdata[:, 0]
+    assert p.N == 400 and p.n_obs[0] == 2 and col[bt.F_H] == 0.1
+    assert col[bt.F_LBX + 3] == 0.0 and col[bt.F_UBX + 2] == np.pi and col[bt.F_LBX] == -100.0
+    assert col[bt.F_LG] == -1e9 and col[bt.F_UH] == 1e9 and col[bt.F_LH] == 0.0
+    assert col[bt.F_OBS + 2] == 25.0 and col[bt.F_OBS + 3] == 7.0
+    np.testing.assert_allclose(col[bt.F_UBXE:bt.F_UBXE + 5] - col[bt.F_LBXE:bt.F_LBXE + 5],
+                               [0.2, 0.2, 0.02, 0.02, 0.02], atol=1e-12)
+    # corridor rows: -a1 x - c1 y <= b1 ; a2 x + c2 y <= -b2, half-width = corridor_width
+    c1, a1, b1, c2, a2, b2 = corridor_cal((-20, 20), (20, -20), 10.0)
+    assert col[bt.F_CG:bt.F_CG + 4].tolist() == [-a1, -c1, a2, c2] and col[bt.F_UG] == b1 and col[bt.F_UG + 1] == -b2
+    e = EgoConfig()
+    e.obstacles = [[0, 0, 1, 0]] * 5
+    with pytest.raises(ValueError):
+        bt.pack_problems([e], sim)
+
+
+def test_grid_order_and_skip():
+    starts, total = grid_start_states(0.0, 0.0, 0.0, 40, 20, 4)
+    assert total == 36 and len(starts) == 32
+    assert starts[0] == (-20.0, -20.0, 0.0) and starts[1][2] == np.pi / 2
+    assert all(not (x == 0 and y == 0) for x, y, _ in starts)
+    starts, total = grid_start_states(0.0, 0.0, 0.0)            # function defaults
+    assert total == 21 * 21 * 8 and len(starts) == 3520
+    # exactly 1 m away is NOT skipped (strict <)
+    assert (1.0, 0.0, 0.0) in starts
+
+
+def test_grouping_and_order_with_mixed_horizons(oracle):
+    names = ["E_to_F", "line", "C_to_D", "lanechg" if False else "line_change"]
+    pairs = [cases.make_scenario(n) for n in names]
+    egos, sims = [p[0] for p in pairs], [p[1] for p in pairs]
+    st, si, qi, res = solve_groups(egos, sims, solver=oracle.solve_packed)
+    assert [r["x"].shape[0] for r in res] == [151, 151, 221, 221]
+    for (ego, sim), r in zip(pairs, res):
+        single = generate_controls(ego, sim, solver=oracle.solve_packed)
+        assert np.array_equal(single["x"], r["x"]) and np.array_equal(single["u"], r["u"])
+        assert single["t"][-1] == sim.duration and single["status"] == 0
+
+
+def test_failure_contract(oracle, capsys):
+    e = EgoConfig()
+    e.state_start = [0, 0, 0, 0, 0]
+    e.state_final = [90, 90, 0, 0, 0]          # unreachable in 5 s
+    e.verbose = False
+    s = SimConfig()
+    s.duration = 5.0
+    assert find_path(e, s, solver=oracle.solve_packed) is None
+    assert generate_controls(e, s, solver=oracle.solve_packed) is None
+    assert "Solver failed with status" in capsys.readouterr().out
+    e2 = EgoConfig()
+    e2.state_start = [0, 0, 0, 0, 0]
+    e2.state_final = [0, 0, 0, 0, 0]           # start == goal: corridor_cal raises, find_path swallows it
+    e2.verbose = False
+    assert find_paths([e2], s, solver=oracle.solve_packed) == [None]
+
+
+def test_no_silent_cpu_fallback():
+    """Without a HIP device the product path must raise, not compute."""
+    from mpc_amd import _lib
+    lib = _lib.load_library()
+    if lib.mpcx_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(_lib.MpcxError):
+        _lib.solve_packed(synthetic_batch(4))
+    e, s = cases.make_scenario("line")
+    with pytest.raises(_lib.MpcxError):
+        generate_controls(e, s)
+    assert find_path(e, s) is None             # find_path never raises (reference :559-562)

@@ -1,0 +1,102 @@
+"""The CPU oracle against the reference's own recorded outcomes
+(tests/golden/reference_pins.json: values transcribed from the reference's
+docs/*.npy result files, which numpy's safe loader refuses to open).
+
+Tolerance 1e-3 absolute: the reference solves with acados tol = 1e-3
+(core_solver.py:252), so two correct solvers agree to about that.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mpc_amd.core_solver import solve_groups
+from mpc_amd.scenarios import run_sequential_planning, sequential_segments
+from mpc_amd.grid_path_plan import grid_path_planning
+
+import cases
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PINS = json.load(open(os.path.join(HERE, "golden", "reference_pins.json")))
+TOL = PINS["tolerance"]
+
+
+def _solve(name, oracle):
+    ego, sim = cases.make_scenario(name)
+    st, si, qi, res = solve_groups([ego], [sim], solver=oracle.solve_packed)
+    return int(st[0]), res[0]
+
+
+@pytest.mark.parametrize("name", ["line", "E_to_F"])
+def test_value_pins(oracle, name):
+    pin = PINS[name]
+    status, r = _solve(name, oracle)
+    assert status == pin["status"]
+    assert r["x"].shape == (pin["N"] + 1, 5) and r["u"].shape == (pin["N"], 2)
+    np.testing.assert_allclose(r["x"][1], pin["x1"], atol=TOL)
+    np.testing.assert_allclose(r["u"][0], pin["u0"], atol=TOL)
+    np.testing.assert_allclose(r["u"][-1], pin["u_last"], atol=TOL)
+    np.testing.assert_allclose(r["x"][-1], pin["xN"], atol=TOL)
+
+
+def test_active_faces_and_saturation(oracle):
+    status, r = _solve("B_to_C", oracle)
+    pin = PINS["B_to_C"]
+    assert status == 0 and r["x"].shape[0] == pin["N"] + 1
+    assert abs(r["x"][-1, 2] - pin["xN_theta"]) < TOL      # terminal heading on its +eps face
+    assert abs(r["x"][-1, 3] - pin["xN_v"]) < TOL          # terminal speed on its -eps face
+    assert abs(r["x"][-1, 4] - pin["xN_delta"]) < TOL
+    assert abs(np.abs(r["x"][:, 4]).max() - pin["steering_saturates"]) < TOL
+    status, r = _solve("D_to_E", oracle)
+    assert status == 0 and abs(np.abs(r["x"][:, 4]).max() - 0.5) < TOL
+    status, r = _solve("A_to_B", oracle)
+    assert status == 0 and r["x"][0, 2] == PINS["A_to_B"]["x0_theta"]   # +pi stored as -pi, on the bound
+
+
+def test_trajectories_satisfy_rk4(oracle):
+    """Stored reference trajectories satisfy one RK4 step per interval to 4e-6;
+    so must ours (at tol 1e-3 the dynamics gap is below the equality tolerance)."""
+    import ctypes as C
+    lib = oracle.load()
+    status, r = _solve("C_to_D", oracle)
+    assert status == 0
+    x, u = r["x"], r["u"]
+    gap = 0.0
+    for k in range(u.shape[0]):
+        xn = np.zeros(5); A = np.zeros(25); Bm = np.zeros(10)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        lib.mpcx_oracle_rk4(0.1, 2.7, dp(np.ascontiguousarray(x[k])), dp(np.ascontiguousarray(u[k])), dp(xn), dp(A), dp(Bm))
+        gap = max(gap, np.abs(xn - x[k + 1]).max())
+    assert gap < 1e-3
+
+
+def test_sequential_plan_shapes(oracle):
+    combined, ok = run_sequential_planning(sequential_segments, solver=oracle.solve_packed)
+    pin = PINS["sequential"]
+    assert ok and combined["status"] == 0
+    assert [s["results"]["x"].shape[0] for s in combined["segments"]] == pin["segment_x_rows"]
+    assert combined["t"].shape == (pin["stitched_t"],)
+    assert list(combined["x"].shape) == pin["stitched_x"]
+    assert list(combined["u"].shape) == pin["stitched_u"]      # u[1:] dropped too (reference :132)
+    assert np.all(np.diff(combined["t"]) > 0)
+
+
+def test_grid_sweep_outcome(oracle):
+    pin = PINS["grid_default_cli"]
+    res = grid_path_planning(0.0, 0.0, 0.0, grid_size=40, grid_step=20, num_angles=4,
+                             solver=oracle.solve_packed, verbose=False)
+    assert len(res) == pin["successful"] == pin["attempted"]
+    assert res[0]["results"]["x"].shape == (pin["N"] + 1, 5)
+    assert min(r["results"]["x"][:, 3].min() for r in res) < -0.1    # reversing is visible in the reference plot
+
+
+def test_path_finder_clears_obstacles(oracle):
+    ego, sim = cases.make_scenario("path_finder")
+    st, _, _, res = solve_groups([ego], [sim], solver=oracle.solve_packed)
+    assert st[0] == 0
+    x = res[0]["x"]
+    for ox, oy, rad, margin in ego.obstacles:
+        d = np.hypot(x[1:-1, 0] - ox, x[1:-1, 1] - oy)
+        assert d.min() >= rad + margin - 1e-3
+    assert x[:, 3].min() >= -1e-3 and x[:, 3].max() < 3.0
