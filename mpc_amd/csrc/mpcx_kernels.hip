@@ -104,6 +104,7 @@ struct Lane {
                           // of lane l is wave[(k*F + f) * 64 + l]
     const gdouble *pdata; // problem table (same in all lanes); field f of problem b at [f*B + b]
     size_t B;
+    bool writer;          // single-problem mode: this lane performs the stores of uniform data
     unsigned lane;        // 0..63
     unsigned b;           // problem this lane is solving
     int N;
@@ -617,21 +618,23 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) stw(L, k, M::QPI + i, 0.0);
-    // objective
+    // objective: summed per stage, then over the stages
+    double ck = 0.0;
     if (KIND != LAST) {
 #pragma unroll
         for (int j = 0; j < NZ; ++j) {
             double z = (j < NU) ? uk[j] : (xk[j - NU] - pc.get(C_GOAL + j - NU));
             double hw = (0.5 * L.h) * pc.get(C_W + j);
-            a.cost = fma(hw * z, z, a.cost);
+            ck = fma(hw * z, z, ck);
         }
     } else {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             double z = xk[i] - pc.get(C_GOAL + i);
-            a.cost = fma((0.5 * pc.get(C_WE + i)) * z, z, a.cost);
+            ck = fma((0.5 * pc.get(C_WE + i)) * z, z, ck);
         }
     }
+    a.cost = a.cost + ck;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         xk[i] = xn1[i];
@@ -678,16 +681,32 @@ struct Step {          // the interior-point step waiting to be applied
 DEV constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 DEV double psym(const double *P, int i, int j) { return (i >= j) ? P[tri(i, j)] : P[tri(j, i)]; }
 
-struct B0Carry {
-    double Pn[15], pn[NX], vxn[NX], qpin[NX];
-    double ng, nb, nd, nm, sum;
+// what the row part of a B0 stage hands to the Riccati part (and, for vx / qpi, to stage k-1)
+struct B0Out {
+    double gt[NZ], Ht[NZ], hxx, hxy, hyy, rb[NX];
+    AB ab;
+    double vx[NX], qpi[NX];
+    double ng, nb, nd, nm, ssum;
 };
+constexpr int B0OUT_BCAST = NZ + NZ + 3 + NX + 14;      // leading doubles the Riccati part reads
 
-// B0: apply the pending step, residuals of the new iterate, barrier Hessian and
-// affine right-hand side, Riccati factorisation and backward substitution
-template <int NH, int KIND>
-DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, const Step &sp, B0Carry &cy)
+// store by the lanes that own the data: every lane in lane-per-problem mode, one lane
+// when the wavefront works on a single problem and all lanes hold the same value
+template <bool COOP>
+DEV void stwc(const Lane &L, int k, int f, double v)
 {
+    if (!COOP) stw(L, k, f, v);
+    else if (L.writer) stw(L, k, f, v);
+}
+
+// B0, row part of stage k: applies the pending step to the stage's iterate, then residuals,
+// barrier Hessian and affine right-hand side.  vxn / qpin: updated x-part of v and dynamics
+// multiplier of stage k+1.
+template <int NH, int KIND>
+DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, const Step &sp,
+                       const double *vxn, const double *qpin, B0Out &out)
+{
+    out.ng = out.nb = out.nd = out.nm = 0.0;
     typedef Map<NH> M;
     // ---- loads ----
     const int sol = (sp.mode == 2) ? M::SOL2 : 0;      // which of the two stored solutions is the step
@@ -745,7 +764,7 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
     cost_terms<NH, KIND>(L, o, pc, x, u, g, Ht);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) rg[j] = fma(Ht[j], v[j], g[j]);
-    if (KIND != LAST) add_BAt(L, ab, cy.qpin, rg);
+    if (KIND != LAST) add_BAt(L, ab, qpin, rg);
     if (KIND != FIRST) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) rg[NU + i] = rg[NU + i] - qpi[i];
@@ -795,12 +814,12 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
         }
         double rdl = (dlo - jv) + t_l;
         double rdu = (jv - dup) + t_u;
-        double nd = dmax(dmax(cy.nd, dabs(rdl)), dabs(rdu));
+        double nd = dmax(dmax(out.nd, dabs(rdl)), dabs(rdu));
         double ml = l_l * t_l, mu_ = l_u * t_u;
-        double nm = dmax(dmax(cy.nm, dabs(ml)), dabs(mu_));
+        double nm = dmax(dmax(out.nm, dabs(ml)), dabs(mu_));
         double sum = (ssum + ml) + mu_;
-        cy.nd = pr ? nd : cy.nd;
-        cy.nm = pr ? nm : cy.nm;
+        out.nd = pr ? nd : out.nd;
+        out.nm = pr ? nm : out.nm;
         ssum = pr ? sum : ssum;
         // affine right-hand side and barrier Hessian
         double til = 1.0 / t_l, tiu = 1.0 / t_u;
@@ -820,12 +839,12 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
             hyy = pr ? fma(wy, jy, hyy) : hyy;
         }
     }
-    cy.sum = cy.sum + ssum;
+    out.ssum = ssum;
     double gt[NZ];
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
         stw(L, k, M::RG + j, rg[j]);
-        if (var_present<KIND>(j)) cy.ng = dmax(cy.ng, dabs(rg[j]));
+        if (var_present<KIND>(j)) out.ng = dmax(out.ng, dabs(rg[j]));
         gt[j] = rg[j];
     }
 #pragma unroll
@@ -838,6 +857,46 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
             gt[3] = pr ? fma(gjy[r], qrow[r], gt[3]) : gt[3];
         }
     }
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) { out.gt[j] = gt[j]; out.Ht[j] = Ht[j]; }
+    out.hxx = hxx; out.hxy = hxy; out.hyy = hyy;
+    out.ab = ab;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { out.rb[i] = 0.0; out.vx[i] = v[NU + i]; out.qpi[i] = qpi[i]; }
+    if (KIND != LAST) {
+        // dynamics residual
+        mul_AB(L, ab, &v[NU], &v[0], bv, out.rb);
+    #pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            out.rb[i] = out.rb[i] - vxn[i];
+            stw(L, k, M::RB + i, out.rb[i]);
+            out.nb = dmax(out.nb, dabs(out.rb[i]));
+        }
+    }
+}
+
+// updated x-part of v and dynamics multiplier of stage k (what stage_B0_rows of stage k
+// computes for them), for a lane that works on stage k-1 without having processed stage k
+template <int NH>
+DEV void stage_B0_peek(const Lane &L, int k, const Step &sp, double *vx, double *qpi)
+{
+    typedef Map<NH> M;
+    const int sol = (sp.mode == 2) ? M::SOL2 : 0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const double v0 = ldw(L, k, M::V + NU + i), d = ldw_lane(L, k, M::DV + NU + i, sol);
+        const double q0 = ldw(L, k, M::QPI + i), dq = ldw_lane(L, k, M::DPI + i, sol);
+        vx[i] = sp.have ? fma(sp.alpha, d, v0) : v0;
+        qpi[i] = sp.have ? fma(sp.alpha, dq, q0) : q0;
+    }
+}
+
+// B0, Riccati part of stage k: factorisation and backward substitution of the affine
+// right-hand side; Pn, pn hold P(k+1), p(k+1) on entry and P(k), p(k) on return
+template <int NH, int KIND, bool COOP>
+DEV void stage_B0_ric(const Lane &L, int k, const B0Out &in, double *Pn, double *pn)
+{
+    typedef Map<NH> M;
     if (KIND == LAST) {
         // P_N = barrier Hessian of the terminal state, p_N = its right-hand side
 #pragma unroll
@@ -845,45 +904,36 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
 #pragma unroll
             for (int j = 0; j <= i; ++j) {
                 double e = 0.0;
-                if (i == j) e = (i == 0) ? Ht[2] + hxx : (i == 1) ? Ht[3] + hyy : Ht[NU + i];
-                else if (i == 1 && j == 0) e = hxy;
-                cy.Pn[tri(i, j)] = e;
+                if (i == j) e = (i == 0) ? in.Ht[2] + in.hxx : (i == 1) ? in.Ht[3] + in.hyy : in.Ht[NU + i];
+                else if (i == 1 && j == 0) e = in.hxy;
+                Pn[tri(i, j)] = e;
             }
 #pragma unroll
-        for (int i = 0; i < NX; ++i) cy.pn[i] = gt[NU + i];
+        for (int i = 0; i < NX; ++i) pn[i] = in.gt[NU + i];
     } else {
-        // dynamics residual
-        double rb[NX];
-        mul_AB(L, ab, &v[NU], &v[0], bv, rb);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            rb[i] = rb[i] - cy.vxn[i];
-            stw(L, k, M::RB + i, rb[i]);
-            cy.nb = dmax(cy.nb, dabs(rb[i]));
-        }
         // w = p(k+1) + P(k+1) rb
         double w[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            double acc = psym(cy.Pn, i, 0) * rb[0];
+            double acc = psym(Pn, i, 0) * in.rb[0];
 #pragma unroll
-            for (int j = 1; j < NX; ++j) acc = fma(psym(cy.Pn, i, j), rb[j], acc);
-            stw(L, k, M::PRB + i, acc);
-            w[i] = cy.pn[i] + acc;
+            for (int j = 1; j < NX; ++j) acc = fma(psym(Pn, i, j), in.rb[j], acc);
+            stwc<COOP>(L, k, M::PRB + i, acc);
+            w[i] = pn[i] + acc;
         }
         // PBA = P(k+1) [B A]; columns 0,1 = B, 2..6 = A
         double PBA[NX][NZ];
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const double p0 = psym(cy.Pn, i, 0), p1 = psym(cy.Pn, i, 1), p2 = psym(cy.Pn, i, 2),
-                         p3 = psym(cy.Pn, i, 3), p4 = psym(cy.Pn, i, 4);
-            PBA[i][0] = fma(p3, L.hB, fma(p2, ab.b20, fma(p1, ab.b10, p0 * ab.b00)));
-            PBA[i][1] = fma(p4, L.hB, fma(p2, ab.b21, fma(p1, ab.b11, p0 * ab.b01)));
+            const double p0 = psym(Pn, i, 0), p1 = psym(Pn, i, 1), p2 = psym(Pn, i, 2),
+                         p3 = psym(Pn, i, 3), p4 = psym(Pn, i, 4);
+            PBA[i][0] = fma(p3, L.hB, fma(p2, in.ab.b20, fma(p1, in.ab.b10, p0 * in.ab.b00)));
+            PBA[i][1] = fma(p4, L.hB, fma(p2, in.ab.b21, fma(p1, in.ab.b11, p0 * in.ab.b01)));
             PBA[i][2] = p0;
             PBA[i][3] = p1;
-            PBA[i][4] = fma(p1, ab.a12, p0 * ab.a02) + p2;
-            PBA[i][5] = fma(p2, ab.a23, fma(p1, ab.a13, p0 * ab.a03)) + p3;
-            PBA[i][6] = fma(p2, ab.a24, fma(p1, ab.a14, p0 * ab.a04)) + p4;
+            PBA[i][4] = fma(p1, in.ab.a12, p0 * in.ab.a02) + p2;
+            PBA[i][5] = fma(p2, in.ab.a23, fma(p1, in.ab.a13, p0 * in.ab.a03)) + p3;
+            PBA[i][6] = fma(p2, in.ab.a24, fma(p1, in.ab.a14, p0 * in.ab.a04)) + p4;
         }
         // M = Ht + [B A]' PBA, lower triangle
         double Mm[NZ][NZ];
@@ -892,26 +942,26 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
 #pragma unroll
             for (int r = c; r < NZ; ++r) {
                 double acc = 0.0;
-                if (r == c) acc = (r == 2) ? Ht[2] + hxx : (r == 3) ? Ht[3] + hyy : Ht[r];
-                else if (r == 3 && c == 2) acc = hxy;
+                if (r == c) acc = (r == 2) ? in.Ht[2] + in.hxx : (r == 3) ? in.Ht[3] + in.hyy : in.Ht[r];
+                else if (r == 3 && c == 2) acc = in.hxy;
                 if (r == 0)
-                    acc = fma(L.hB, PBA[3][c], fma(ab.b20, PBA[2][c], fma(ab.b10, PBA[1][c], fma(ab.b00, PBA[0][c], acc))));
+                    acc = fma(L.hB, PBA[3][c], fma(in.ab.b20, PBA[2][c], fma(in.ab.b10, PBA[1][c], fma(in.ab.b00, PBA[0][c], acc))));
                 else if (r == 1)
-                    acc = fma(L.hB, PBA[4][c], fma(ab.b21, PBA[2][c], fma(ab.b11, PBA[1][c], fma(ab.b01, PBA[0][c], acc))));
+                    acc = fma(L.hB, PBA[4][c], fma(in.ab.b21, PBA[2][c], fma(in.ab.b11, PBA[1][c], fma(in.ab.b01, PBA[0][c], acc))));
                 else if (r == 2) acc = acc + PBA[0][c];
                 else if (r == 3) acc = acc + PBA[1][c];
-                else if (r == 4) acc = fma(ab.a12, PBA[1][c], fma(ab.a02, PBA[0][c], acc)) + PBA[2][c];
-                else if (r == 5) acc = fma(ab.a23, PBA[2][c], fma(ab.a13, PBA[1][c], fma(ab.a03, PBA[0][c], acc))) + PBA[3][c];
-                else acc = fma(ab.a24, PBA[2][c], fma(ab.a14, PBA[1][c], fma(ab.a04, PBA[0][c], acc))) + PBA[4][c];
+                else if (r == 4) acc = fma(in.ab.a12, PBA[1][c], fma(in.ab.a02, PBA[0][c], acc)) + PBA[2][c];
+                else if (r == 5) acc = fma(in.ab.a23, PBA[2][c], fma(in.ab.a13, PBA[1][c], fma(in.ab.a03, PBA[0][c], acc))) + PBA[3][c];
+                else acc = fma(in.ab.a24, PBA[2][c], fma(in.ab.a14, PBA[1][c], fma(in.ab.a04, PBA[0][c], acc))) + PBA[4][c];
                 Mm[r][c] = acc;
             }
         }
         const double d0 = 1.0 / Mm[0][0];                          // reciprocal pivots
         const double l10 = Mm[1][0] * d0;
         const double d1 = 1.0 / fma(-l10, Mm[1][0], Mm[1][1]);
-        stw(L, k, M::LDL + 0, l10);
-        stw(L, k, M::LDL + 1, d0);
-        stw(L, k, M::LDL + 2, d1);
+        stwc<COOP>(L, k, M::LDL + 0, l10);
+        stwc<COOP>(L, k, M::LDL + 1, d0);
+        stwc<COOP>(L, k, M::LDL + 2, d1);
         double Kg[NU][NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -921,41 +971,36 @@ DEV void stage_B0(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, co
             double s0 = fma(-l10, z1, z0);
             Kg[0][i] = -s0;
             Kg[1][i] = -z1;
-            stw(L, k, M::K + i, Kg[0][i]);
-            stw(L, k, M::K + NX + i, Kg[1][i]);
+            stwc<COOP>(L, k, M::K + i, Kg[0][i]);
+            stwc<COOP>(L, k, M::K + NX + i, Kg[1][i]);
         }
         // right-hand side of this stage and feed-forward
         double m[NZ];
 #pragma unroll
-        for (int j = 0; j < NZ; ++j) m[j] = gt[j];
-        add_BAt(L, ab, w, m);
+        for (int j = 0; j < NZ; ++j) m[j] = in.gt[j];
+        add_BAt(L, in.ab, w, m);
         {
             double y0 = m[0];
             double y1 = fma(-l10, y0, m[1]);
             double z0 = y0 * d0, z1 = y1 * d1;
             double s0 = fma(-l10, z1, z0);
-            stw(L, k, M::KV + 0, -s0);
-            stw(L, k, M::KV + 1, -z1);
+            stwc<COOP>(L, k, M::KV + 0, -s0);
+            stwc<COOP>(L, k, M::KV + 1, -z1);
         }
 #pragma unroll
-        for (int i = 0; i < NX; ++i) cy.pn[i] = fma(Kg[1][i], m[1], fma(Kg[0][i], m[0], m[NU + i]));
+        for (int i = 0; i < NX; ++i) pn[i] = fma(Kg[1][i], m[1], fma(Kg[0][i], m[0], m[NU + i]));
         // P(k) = M_xx + M_xu K
 #pragma unroll
         for (int i = 0; i < NX; ++i)
 #pragma unroll
             for (int j = 0; j <= i; ++j) {
                 double e = fma(Mm[NU + i][0], Kg[0][j], Mm[NU + i][NU + j]);
-                cy.Pn[tri(i, j)] = fma(Mm[NU + i][1], Kg[1][j], e);
+                Pn[tri(i, j)] = fma(Mm[NU + i][1], Kg[1][j], e);
             }
     }
     if (KIND != FIRST) {
 #pragma unroll
-        for (int i = 0; i < 15; ++i) stw(L, k, M::P + i, cy.Pn[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        cy.vxn[i] = v[NU + i];
-        cy.qpin[i] = qpi[i];
+        for (int i = 0; i < 15; ++i) stwc<COOP>(L, k, M::P + i, Pn[i]);
     }
 }
 
@@ -967,27 +1012,43 @@ __device__ __attribute__((noinline)) void sweep_B0(Lane L, PC<NH> pc, const mpcx
     Step sp;
     sp.have = sp_have; sp.mode = sp_mode; sp.sigma_mu = sp_sigma_mu; sp.alpha = sp_alpha;
     const int N = L.N;
-    B0Carry cy;
+    double Pn[15], pn[NX], vxn[NX], qpin[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { cy.pn[i] = 0.0; cy.vxn[i] = 0.0; cy.qpin[i] = 0.0; }
+    for (int i = 0; i < NX; ++i) { pn[i] = 0.0; vxn[i] = 0.0; qpin[i] = 0.0; }
 #pragma unroll
-    for (int i = 0; i < 15; ++i) cy.Pn[i] = 0.0;
-    cy.ng = cy.nb = cy.nd = cy.nm = cy.sum = 0.0;
-    stage_B0<NH, LAST>(L, o, pc, N, sp, cy);
-    for (int k = N - 1; k >= 1; --k) stage_B0<NH, MID>(L, o, pc, k, sp, cy);
-    stage_B0<NH, FIRST>(L, o, pc, 0, sp, cy);
-    ret[0 * 64] = cy.ng; ret[1 * 64] = cy.nb; ret[2 * 64] = cy.nd; ret[3 * 64] = cy.nm;
-    ret[4 * 64] = cy.sum / (double)m_total;
+    for (int i = 0; i < 15; ++i) Pn[i] = 0.0;
+    double ng = 0.0, nb = 0.0, nd = 0.0, nm = 0.0, sum = 0.0;
+#define B0_STAGE(KIND, kk)                                                             \
+    {                                                                                  \
+        B0Out t;                                                                       \
+        stage_B0_rows<NH, KIND>(L, o, pc, kk, sp, vxn, qpin, t);                       \
+        stage_B0_ric<NH, KIND, false>(L, kk, t, Pn, pn);                               \
+        ng = dmax(ng, t.ng); nb = dmax(nb, t.nb); nd = dmax(nd, t.nd); nm = dmax(nm, t.nm); \
+        sum = sum + t.ssum;                                                            \
+        _Pragma("unroll") for (int i = 0; i < NX; ++i) { vxn[i] = t.vx[i]; qpin[i] = t.qpi[i]; } \
+    }
+    B0_STAGE(LAST, N)
+    for (int k = N - 1; k >= 1; --k) B0_STAGE(MID, k)
+    B0_STAGE(FIRST, 0)
+#undef B0_STAGE
+    ret[0 * 64] = ng; ret[1 * 64] = nb; ret[2 * 64] = nd; ret[3 * 64] = nm;
+    ret[4 * 64] = sum / (double)m_total;
 }
 
 // Bs: right-hand sides of the corrector (1) and of the centring-only step (2), both
 // substituted backwards with the stored factors in the same pass over the data
+struct BsOut {
+    double gt1[NZ], gt2[NZ], prb[NX], k0[NX], k1[NX], l10, d0, d1;
+    AB ab;
+};
+
+// Bs, row part of stage k: the two right-hand sides, and the stored factors of the stage
 template <int NH, int KIND>
-DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu,
-                  double *pn1, double *pn2)
+DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu, BsOut &out)
 {
     typedef Map<NH> M;
-    double x[NX], u[NU], v[NZ], dva[NZ], gt1[NZ], gt2[NZ];
+    double x[NX], u[NU], v[NZ], dva[NZ];
+    double *gt1 = out.gt1, *gt2 = out.gt2;
     double ll[M::R], lu[M::R], tl[M::R], tu[M::R], til_[M::R], tiu_[M::R];
     load_xu<NH, KIND>(L, k, x, u);
 #pragma unroll
@@ -1007,19 +1068,21 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, do
         til_[r] = ldw(L, k, M::TIL + r);
         tiu_[r] = ldw(L, k, M::TIU + r);
     }
-    AB ab = {};
-    double prb[NX], l10 = 0.0, d0 = 1.0, d1 = 1.0, k0[NX], k1[NX];
+    out.ab = AB{};
+    out.l10 = 0.0; out.d0 = 1.0; out.d1 = 1.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { out.prb[i] = 0.0; out.k0[i] = 0.0; out.k1[i] = 0.0; }
     if (KIND != LAST) {
-        load_ab<NH>(L, k, ab);
+        load_ab<NH>(L, k, out.ab);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            prb[i] = ldw(L, k, M::PRB + i);
-            k0[i] = ldw(L, k, M::K + i);
-            k1[i] = ldw(L, k, M::K + NX + i);
+            out.prb[i] = ldw(L, k, M::PRB + i);
+            out.k0[i] = ldw(L, k, M::K + i);
+            out.k1[i] = ldw(L, k, M::K + NX + i);
         }
-        l10 = ldw(L, k, M::LDL + 0);
-        d0 = ldw(L, k, M::LDL + 1);
-        d1 = ldw(L, k, M::LDL + 2);
+        out.l10 = ldw(L, k, M::LDL + 0);
+        out.d0 = ldw(L, k, M::LDL + 1);
+        out.d1 = ldw(L, k, M::LDL + 2);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1054,34 +1117,51 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, do
             gt2[3] = pr ? fma(jy, q2, gt2[3]) : gt2[3];
         }
     }
+}
+
+// Bs, recursion part of stage k: pn1 / pn2 hold p(k+1) of the two systems on entry, p(k) on return
+template <int NH, int KIND, bool COOP>
+DEV void stage_Bs_rec(const Lane &L, int k, const BsOut &in, double *pn1, double *pn2)
+{
+    typedef Map<NH> M;
     if (KIND == LAST) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { pn1[i] = gt1[NU + i]; pn2[i] = gt2[NU + i]; }
+        for (int i = 0; i < NX; ++i) { pn1[i] = in.gt1[NU + i]; pn2[i] = in.gt2[NU + i]; }
     } else {
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
             double *pn = sidx ? pn2 : pn1;
-            double *gt = sidx ? gt2 : gt1;
+            const double *gt = sidx ? in.gt2 : in.gt1;
             double w[NX], m[NZ];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) w[i] = pn[i] + prb[i];
+            for (int i = 0; i < NX; ++i) w[i] = pn[i] + in.prb[i];
 #pragma unroll
             for (int j = 0; j < NZ; ++j) m[j] = gt[j];
-            add_BAt(L, ab, w, m);
+            add_BAt(L, in.ab, w, m);
             double y0 = m[0];
-            double y1 = fma(-l10, y0, m[1]);
-            double z0 = y0 * d0, z1 = y1 * d1;
-            double s0 = fma(-l10, z1, z0);
-            stw(L, k, (sidx ? M::KV2 : M::KV) + 0, -s0);
-            stw(L, k, (sidx ? M::KV2 : M::KV) + 1, -z1);
+            double y1 = fma(-in.l10, y0, m[1]);
+            double z0 = y0 * in.d0, z1 = y1 * in.d1;
+            double s0 = fma(-in.l10, z1, z0);
+            stwc<COOP>(L, k, (sidx ? M::KV2 : M::KV) + 0, -s0);
+            stwc<COOP>(L, k, (sidx ? M::KV2 : M::KV) + 1, -z1);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) pn[i] = fma(k1[i], m[1], fma(k0[i], m[0], m[NU + i]));
+            for (int i = 0; i < NX; ++i) pn[i] = fma(in.k1[i], m[1], fma(in.k0[i], m[0], m[NU + i]));
         }
     }
     if (KIND != FIRST) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { stw(L, k, M::PV + i, pn1[i]); stw(L, k, M::PV2 + i, pn2[i]); }
+        for (int i = 0; i < NX; ++i) { stwc<COOP>(L, k, M::PV + i, pn1[i]); stwc<COOP>(L, k, M::PV2 + i, pn2[i]); }
     }
+}
+
+
+template <int NH, int KIND>
+DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu,
+                  double *pn1, double *pn2)
+{
+    BsOut t;
+    stage_Bs_rows<NH, KIND>(L, o, pc, k, sigma_mu, t);
+    stage_Bs_rec<NH, KIND, false>(L, k, t, pn1, pn2);
 }
 
 template <int NH>
@@ -1103,15 +1183,30 @@ __device__ __attribute__((noinline)) void sweep_Bs(Lane L, PC<NH> pc, const mpcx
 // and the centring-only step side by side: stores both (DV, DPI and DV2, DPI2)
 // and returns both lengths.
 // ---------------------------------------------------------------------------
-// the longest feasible step is num/den: the smallest ratio met so far, kept as a pair and
-// compared by cross multiplication so that a sweep needs one division only
-struct FAcc { double num[2], den[2], s1, s2; };
+// the longest feasible step of a stage is num/den: the smallest ratio met in the stage, kept
+// as a pair and compared by cross multiplication (one division per stage); the step of the
+// sweep is the minimum over the stages, which does not depend on the order of the stages
+struct FAcc { double alpha[2], s1, s2; };
 
 DEV void ratio_min(double val, double step, double &num, double &den)
 {
     const bool c = (step < 0.0) && (val * den < num * (-step));
     num = c ? val : num;
     den = c ? -step : den;
+}
+
+// forward recursion of one stage: du = kv + K dx, dxn = A dx + B du + rb
+DEV void F_rec(const Lane &L, const AB &ab, const double (*kg)[NX], const double *kv, const double *rb,
+               const double *dx, double *du, double *dxn)
+{
+#pragma unroll
+    for (int c = 0; c < NU; ++c) {
+        double acc = kv[c];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) acc = fma(kg[c][i], dx[i], acc);
+        du[c] = acc;
+    }
+    mul_AB(L, ab, dx, du, rb, dxn);
 }
 
 template <int NH, int KIND, int NS>
@@ -1179,19 +1274,14 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, dou
             }
         }
         if (KIND != LAST) {
-#pragma unroll
-            for (int c = 0; c < NU; ++c) {
-                double acc = kv[q][c];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) acc = fma(kg[c][i], dx[q][i], acc);
-                dvk[q][c] = acc;
-            }
-            mul_AB(L, ab, dx[q], dvk[q], rb, dxn[q]);
+            F_rec(L, ab, kg, kv[q], rb, dx[q], dvk[q], dxn[q]);
         }
 #pragma unroll
         for (int j = 0; j < NZ; ++j) stw(L, k, (NS == 1 ? M::DVA : M::DV + q * M::SOL2) + j, dvk[q][j]);
     }
-    double s1k = 0.0, s2k = 0.0;
+    double s1k = 0.0, s2k = 0.0, knum[NS], kden[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { knum[q] = 1.0; kden[q] = 1.0; }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
         if (!row_present<KIND>(r)) continue;
@@ -1224,13 +1314,13 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, dou
             double dtu = -jd - rdu;
             double dll = -(fma(ll[r], dtl, rml[q]) * til);
             double dlu = -(fma(lu[r], dtu, rmu[q]) * tiu);
-            double num = a.num[q], den = a.den[q];
+            double num = knum[q], den = kden[q];
             ratio_min(ll[r], dll, num, den);
             ratio_min(tl[r], dtl, num, den);
             ratio_min(lu[r], dlu, num, den);
             ratio_min(tu[r], dtu, num, den);
-            a.num[q] = pr ? num : a.num[q];
-            a.den[q] = pr ? den : a.den[q];
+            knum[q] = pr ? num : knum[q];
+            kden[q] = pr ? den : kden[q];
             if (NS == 1) {
                 double s1 = s1k, s2 = s2k;
                 s1 = fma(ll[r], dtl, s1);
@@ -1246,6 +1336,11 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, dou
     }
     if (NS == 1) { a.s1 = a.s1 + s1k; a.s2 = a.s2 + s2k; }
 #pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        const double ak = knum[q] / kden[q];       // longest step of this stage; the step is the min over stages
+        a.alpha[q] = (ak < a.alpha[q]) ? ak : a.alpha[q];
+    }
+#pragma unroll
     for (int q = 0; q < NS; ++q)
 #pragma unroll
         for (int i = 0; i < NX; ++i) dx[q][i] = dxn[q][i];
@@ -1258,7 +1353,7 @@ __device__ __attribute__((noinline)) double sweep_F(Lane L, PC<NH> pc, const mpc
 {
     const mpcx_opts &o = *op;
     const int N = L.N;
-    FAcc a = {{1.0, 1.0}, {1.0, 1.0}, 0.0, 0.0};
+    FAcc a = {{1.0, 1.0}, 0.0, 0.0};
     double dx[NS][NX];
 #pragma unroll
     for (int q = 0; q < NS; ++q)
@@ -1268,8 +1363,8 @@ __device__ __attribute__((noinline)) double sweep_F(Lane L, PC<NH> pc, const mpc
     for (int k = 1; k < N; ++k) stage_F<NH, MID, NS>(L, o, pc, k, sigma_mu, dx, a);
     stage_F<NH, LAST, NS>(L, o, pc, N, sigma_mu, dx, a);
     if (NS == 1) { ret[0 * 64] = a.s1; ret[1 * 64] = a.s2; }
-    else ret[0 * 64] = a.num[1] / a.den[1];
-    return a.num[0] / a.den[0];
+    else ret[0 * 64] = a.alpha[1];
+    return a.alpha[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -1337,6 +1432,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     L.pdata = (const gdouble *)in.pdata;
     L.B = (size_t)in.B;
     L.lane = threadIdx.x;
+    L.writer = true;
     L.b = 0;
     L.N = N;
     L.F = M::F;

@@ -672,11 +672,12 @@ static real qp_step_length(const problem *pb, stage *st, int mode, real sigma_mu
     const int N = pb->N;
     /* The longest feasible step is the smallest ratio n/d over the sides that
      * move towards zero (n = current value, d = -step > 0).  The running
-     * minimum is kept as the pair (num, den) and candidates are compared by
-     * cross multiplication, so the whole sweep costs one division. */
-    real num = 1.0, den = 1.0, s1 = 0.0, s2 = 0.0;
+     * minimum of a stage is kept as the pair (num, den) and candidates are
+     * compared by cross multiplication, so a stage costs one division. */
+    real alpha = 1.0, s1 = 0.0, s2 = 0.0;
     for (int k = 0; k <= N; ++k) {
         stage *s = &st[k];
+        real num = 1.0, den = 1.0;    /* smallest ratio of this stage; the step is the min over stages */
         real s1k = 0.0, s2k = 0.0;    /* sums of this stage, then added to the totals */
         for (int r = s->r0; r < s->r1; ++r) {
             real til = (real)1.0 / s->t_l[r], tiu = (real)1.0 / s->t_u[r];
@@ -711,10 +712,12 @@ static real qp_step_length(const problem *pb, stage *st, int mode, real sigma_mu
         }
         s1 = s1 + s1k;
         s2 = s2 + s2k;
+        real ak = num / den;
+        if (ak < alpha) alpha = ak;
     }
     if (S1) *S1 = s1;
     if (S2) *S2 = s2;
-    return num / den;
+    return alpha;
 }
 
 static void qp_update(const problem *pb, const mpcx_opts *o, stage *st, int mode,
@@ -815,18 +818,22 @@ static int qp_solve(const problem *pb, const mpcx_opts *o, stage *st, int *iters
 /* ------------------------------------------------------------------ */
 static real nlp_cost(const problem *pb, const stage *st)
 {
-    real c = 0.0;
-    for (int k = 0; k < pb->N; ++k)
+    real c = 0.0;      /* stage costs are summed per stage first, then over the stages */
+    for (int k = 0; k < pb->N; ++k) {
+        real ck = 0.0;
         for (int j = 0; j < NZ; ++j) {
             real z = (j < NU) ? st[k].u[j] : (st[k].x[j - NU] - pb->goal[j - NU]);
             real hw = ((real)0.5 * pb->h) * pb->W[j];
-            c = rfma(hw * z, z, c);
+            ck = rfma(hw * z, z, ck);
         }
+        c = c + ck;
+    }
+    real ce = 0.0;
     for (int i = 0; i < NX; ++i) {
         real z = st[pb->N].x[i] - pb->goal[i];
-        c = rfma(((real)0.5 * pb->We[i]) * z, z, c);
+        ce = rfma(((real)0.5 * pb->We[i]) * z, z, ce);
     }
-    return c;
+    return c + ce;
 }
 
 typedef struct { int status, sqp_iter, qp_iter; real cost, res[4]; } outcome;
