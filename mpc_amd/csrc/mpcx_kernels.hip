@@ -1368,6 +1368,216 @@ __device__ __attribute__((noinline)) double sweep_F(Lane L, PC<NH> pc, const mpc
 }
 
 // ---------------------------------------------------------------------------
+// single-problem mode.  When a wavefront has only a few problems left (the end of
+// a batch, or a call with a handful of problems) one lane per problem leaves the
+// machine waiting on the memory latency of one dependency chain.  The sweeps
+// below work on ONE problem with lane j on stage j (N + 1 <= 64): the row part of
+// every stage runs at once, the recursion over the stages runs once, on values
+// broadcast from the lane that owns the stage, and the reductions visit the stages
+// in the order the one-lane-per-problem sweeps do.  Every number is produced by
+// the same operations in the same order, so which mode ran leaves no trace in
+// the results.
+// ---------------------------------------------------------------------------
+DEV double bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+DEV double uniform(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+DEV double from_next_lane(double v) { return __shfl_down(v, 1, 64); }
+
+DEV AB bcast_ab(const AB &a, int k)
+{
+    AB r;
+    r.a02 = bcast(a.a02, k); r.a03 = bcast(a.a03, k); r.a04 = bcast(a.a04, k);
+    r.a12 = bcast(a.a12, k); r.a13 = bcast(a.a13, k); r.a14 = bcast(a.a14, k);
+    r.a23 = bcast(a.a23, k); r.a24 = bcast(a.a24, k);
+    r.b00 = bcast(a.b00, k); r.b10 = bcast(a.b10, k); r.b20 = bcast(a.b20, k);
+    r.b01 = bcast(a.b01, k); r.b11 = bcast(a.b11, k); r.b21 = bcast(a.b21, k);
+    return r;
+}
+
+// stores of one lane become visible to the loads of the others (same wavefront, same CU)
+DEV void coop_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// C: the problem's Lane with C.lane = its column in the workspace; stage j of it is
+// addressed as stage 0 of a Lane whose "lane" is moved by j stages
+DEV Lane stage_lane(const Lane &C, unsigned j, bool writer)
+{
+    Lane S = C;
+    S.lane = j * (unsigned)(C.F * 64) + C.lane;
+    S.writer = writer;
+    return S;
+}
+
+template <int NH>
+__device__ __attribute__((noinline)) void coop_B0(Lane C, PC<NH> pc, const mpcx_opts *op, bool sp_have, int sp_mode,
+                                                  double sp_sigma_mu, double sp_alpha, int m_total, ldouble *ret)
+{
+    const mpcx_opts &o = *op;
+    Step sp;
+    sp.have = sp_have; sp.mode = sp_mode; sp.sigma_mu = sp_sigma_mu; sp.alpha = sp_alpha;
+    const int N = C.N;
+    const int j = (int)threadIdx.x;
+    const Lane S = stage_lane(C, (unsigned)j, true);
+    coop_sync();
+    // the stage above supplies its updated state and multiplier
+    double vx[NX], qpi[NX], vxn[NX], qpin[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { vx[i] = 0.0; qpi[i] = 0.0; }
+    if (j <= N) stage_B0_peek<NH>(S, 0, sp, vx, qpi);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { vxn[i] = from_next_lane(vx[i]); qpin[i] = from_next_lane(qpi[i]); }
+    B0Out t = {};
+    if (j == 0) stage_B0_rows<NH, FIRST>(S, o, pc, 0, sp, vxn, qpin, t);
+    else if (j < N) stage_B0_rows<NH, MID>(S, o, pc, 0, sp, vxn, qpin, t);
+    else if (j == N) stage_B0_rows<NH, LAST>(S, o, pc, 0, sp, vxn, qpin, t);
+    // recursion and reductions, stage N down to 0
+    double Pn[15], pn[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) pn[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) Pn[i] = 0.0;
+    double ng = 0.0, nb = 0.0, nd = 0.0, nm = 0.0, sum = 0.0;
+    for (int k = N; k >= 0; --k) {
+        B0Out in;
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) { in.gt[i] = bcast(t.gt[i], k); in.Ht[i] = bcast(t.Ht[i], k); }
+        in.hxx = bcast(t.hxx, k); in.hxy = bcast(t.hxy, k); in.hyy = bcast(t.hyy, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) in.rb[i] = bcast(t.rb[i], k);
+        in.ab = bcast_ab(t.ab, k);
+        ng = dmax(ng, bcast(t.ng, k)); nb = dmax(nb, bcast(t.nb, k));
+        nd = dmax(nd, bcast(t.nd, k)); nm = dmax(nm, bcast(t.nm, k));
+        sum = sum + bcast(t.ssum, k);
+        const Lane R = stage_lane(C, (unsigned)k, j == 0);
+        // (stage 0 also stores its P, into a slot nobody reads)
+        if (k == N) stage_B0_ric<NH, LAST, true>(R, 0, in, Pn, pn);
+        else stage_B0_ric<NH, MID, true>(R, 0, in, Pn, pn);
+    }
+    coop_sync();
+    ret[0 * 64] = ng; ret[1 * 64] = nb; ret[2 * 64] = nd; ret[3 * 64] = nm;
+    ret[4 * 64] = sum / (double)m_total;
+}
+
+template <int NH>
+__device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_opts *op, double sigma_mu)
+{
+    const mpcx_opts &o = *op;
+    const int N = C.N;
+    const int j = (int)threadIdx.x;
+    const Lane S = stage_lane(C, (unsigned)j, true);
+    coop_sync();
+    BsOut t = {};
+    if (j == 0) stage_Bs_rows<NH, FIRST>(S, o, pc, 0, sigma_mu, t);
+    else if (j < N) stage_Bs_rows<NH, MID>(S, o, pc, 0, sigma_mu, t);
+    else if (j == N) stage_Bs_rows<NH, LAST>(S, o, pc, 0, sigma_mu, t);
+    double pn1[NX], pn2[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { pn1[i] = 0.0; pn2[i] = 0.0; }
+    for (int k = N; k >= 0; --k) {
+        BsOut in;
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) { in.gt1[i] = bcast(t.gt1[i], k); in.gt2[i] = bcast(t.gt2[i], k); }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            in.prb[i] = bcast(t.prb[i], k); in.k0[i] = bcast(t.k0[i], k); in.k1[i] = bcast(t.k1[i], k);
+        }
+        in.l10 = bcast(t.l10, k); in.d0 = bcast(t.d0, k); in.d1 = bcast(t.d1, k);
+        in.ab = bcast_ab(t.ab, k);
+        const Lane R = stage_lane(C, (unsigned)k, j == 0);
+        if (k == N) stage_Bs_rec<NH, LAST, true>(R, 0, in, pn1, pn2);
+        else if (k > 0) stage_Bs_rec<NH, MID, true>(R, 0, in, pn1, pn2);
+        else stage_Bs_rec<NH, FIRST, true>(R, 0, in, pn1, pn2);
+    }
+    coop_sync();
+}
+
+template <int NH, int NS>
+__device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx_opts *op, double sigma_mu, ldouble *ret)
+{
+    typedef Map<NH> M;
+    const mpcx_opts &o = *op;
+    const int N = C.N;
+    const int j = (int)threadIdx.x;
+    const Lane S = stage_lane(C, (unsigned)j, true);
+    coop_sync();
+    // what the recursion needs of every stage
+    AB ab = {};
+    double rb[NX], kg[NU][NX], kv[NS][NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { rb[i] = 0.0; kg[0][i] = 0.0; kg[1][i] = 0.0; }
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { kv[q][0] = 0.0; kv[q][1] = 0.0; }
+    if (j < N) {
+        load_ab<NH>(S, 0, ab);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            rb[i] = ldw(S, 0, M::RB + i);
+            kg[0][i] = ldw(S, 0, M::K + i);
+            kg[1][i] = ldw(S, 0, M::K + NX + i);
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            kv[q][0] = ldw(S, 0, M::KV + q * M::SOL2 + 0);
+            kv[q][1] = ldw(S, 0, M::KV + q * M::SOL2 + 1);
+        }
+    }
+    // the state step of every stage, kept by the lane of the stage
+    double dx[NS][NX], mydx[NS][NX];
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { dx[q][i] = 0.0; mydx[q][i] = 0.0; }
+    for (int k = 0; k < N; ++k) {
+        const AB abk = bcast_ab(ab, k);
+        double rbk[NX], kgk[NU][NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            rbk[i] = bcast(rb[i], k); kgk[0][i] = bcast(kg[0][i], k); kgk[1][i] = bcast(kg[1][i], k);
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const double kvk[NU] = {bcast(kv[q][0], k), bcast(kv[q][1], k)};
+            double du[NU], dxn[NX];
+            F_rec(C, abk, kgk, kvk, rbk, dx[q], du, dxn);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                dx[q][i] = dxn[i];
+                mydx[q][i] = (j == k + 1) ? dxn[i] : mydx[q][i];
+            }
+        }
+    }
+    FAcc a = {{1.0, 1.0}, 0.0, 0.0};
+    if (j == 0) stage_F<NH, FIRST, NS>(S, o, pc, 0, sigma_mu, mydx, a);
+    else if (j < N) stage_F<NH, MID, NS>(S, o, pc, 0, sigma_mu, mydx, a);
+    else if (j == N) stage_F<NH, LAST, NS>(S, o, pc, 0, sigma_mu, mydx, a);
+    double alpha[2] = {1.0, 1.0}, s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k <= N; ++k) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const double ak = bcast(a.alpha[q], k);
+            alpha[q] = (ak < alpha[q]) ? ak : alpha[q];
+        }
+        if (NS == 1) { s1 = s1 + bcast(a.s1, k); s2 = s2 + bcast(a.s2, k); }
+    }
+    coop_sync();
+    if (NS == 1) { ret[0 * 64] = s1; ret[1 * 64] = s2; }
+    else ret[0 * 64] = alpha[1];
+    return alpha[0];
+}
+
+// ---------------------------------------------------------------------------
 // the fused solve.  Every lane runs a small state machine over its own problem;
 // the wavefront executes the sweeps in a fixed order each TICK and a lane joins
 // the sweeps its state calls for.  A lane whose problem ends takes the next
@@ -1409,6 +1619,11 @@ enum LaneState {
 // back until this many lanes wait for them (or no lane has interior-point work).
 #ifndef MPCX_SERVICE_MIN
 #define MPCX_SERVICE_MIN 8
+#endif
+// With this many problems or fewer in the interior point the wavefront takes them one at a
+// time in single-problem mode.
+#ifndef MPCX_COOP_MAX
+#define MPCX_COOP_MAX 4
 #endif
 
 template <int NH>
@@ -1453,7 +1668,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         const bool wants = (state == LS_OUT) || (state == LS_FETCH) || (state == LS_LIN);
         const int n_wants = __popcll(__ballot(wants));
         const int n_qp = __popcll(__ballot(state == LS_QP));
-        if (n_wants >= MPCX_SERVICE_MIN || n_qp == 0) {
+        const bool few = (N < 64) && (n_qp <= MPCX_COOP_MAX);     // single-problem mode ahead
+        if (n_wants >= MPCX_SERVICE_MIN || n_qp == 0 || (few && n_wants > 0)) {
             const bool st_e = (state == LS_OUT);
             if (state == LS_OUT) {
                 const size_t b = L.b;
@@ -1552,6 +1768,80 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             STAMP(1, st_b);
         }
         if (!__any(state != LS_DONE)) break;
+
+        // ---- few problems left: one interior-point iteration of each, the wavefront on one problem
+        const unsigned long long qp_mask = __ballot(state == LS_QP);
+        if ((N < 64) && __popcll(qp_mask) <= MPCX_COOP_MAX) {
+            for (unsigned long long rest = qp_mask; rest != 0; rest &= rest - 1) {
+                const int p = __ffsll((long long)rest) - 1;
+                Lane C = L;
+                C.lane = (unsigned)p;
+                C.b = (unsigned)__builtin_amdgcn_readlane((int)L.b, p);
+                C.nobs = __builtin_amdgcn_readlane(L.nobs, p);
+                C.h = bcast(L.h, p); C.hh = bcast(L.hh, p); C.h6 = bcast(L.h6, p);
+                C.hB = bcast(L.hB, p); C.invL = bcast(L.invL, p);
+                PC<NH> pcc;
+                pcc.p = (ldouble *)pc_lds + p;
+                pcc.lmk = bcast(pc.lmk, p);
+                Step s;
+                s.have = __builtin_amdgcn_readlane((int)sp.have, p) != 0;
+                s.mode = __builtin_amdgcn_readlane(sp.mode, p);
+                s.sigma_mu = bcast(sp.sigma_mu, p);
+                s.alpha = bcast(sp.alpha, p);
+                const int mt = __builtin_amdgcn_readlane(m_total, p);
+                int qit = __builtin_amdgcn_readlane(qp_it, p);
+                int n_state = LS_QP, n_status = -1, add_total = 0, add_sqp = 0;
+                coop_B0<NH>(C, pcc, op, s.have, s.mode, s.sigma_mu, s.alpha, mt, ret);
+                const double Rg = uniform(ret[0 * 64]), Rb = uniform(ret[1 * 64]), Rd = uniform(ret[2 * 64]),
+                             Rm = uniform(ret[3 * 64]), mu = uniform(ret[4 * 64]);
+                int qs = -1;
+                if (!(finite_d(Rg) && finite_d(Rb) && finite_d(Rd) && finite_d(Rm))) qs = 3;
+                else if (Rg < o.qp_tol_stat && Rb < o.qp_tol_eq && Rd < o.qp_tol_ineq && Rm < o.qp_tol_comp) qs = 0;
+                else if (qit >= o.max_qp_iter) qs = 1;
+                if (qs >= 0) {
+                    add_total = qit;
+                    add_sqp = 1;
+                    if (qs == 3) { n_status = MPCX_QP_FAILURE; n_state = LS_OUT; }
+                    else n_state = LS_LIN;
+                } else {
+                    const double a_aff = uniform(coop_F<NH, 1>(C, pcc, op, 0.0, ret));
+                    const double S1 = uniform(ret[0 * 64]), S2 = uniform(ret[1 * 64]);
+                    double S0 = mu * (double)mt;
+                    double mu_aff = fma(a_aff, fma(a_aff, S2, S1), S0) / (double)mt;
+                    if (mu_aff < 0.0) mu_aff = 0.0;
+                    double ratio = mu_aff / mu;
+                    double sigma = ratio * ratio * ratio;
+                    const double sigma_mu = sigma * mu;
+                    coop_Bs<NH>(C, pcc, op, sigma_mu);
+                    const double alpha1 = uniform(coop_F<NH, 2>(C, pcc, op, sigma_mu, ret));
+                    const double alpha2 = uniform(ret[0 * 64]);
+                    const bool use2 = o.cond_pred_corr && (alpha1 < a_aff);
+                    const double alpha = use2 ? alpha2 : alpha1;
+                    ++qit;
+                    if (!(alpha > o.alpha_min)) {
+                        add_total = qit;
+                        add_sqp = 1;
+                        n_status = MPCX_QP_FAILURE;
+                        n_state = LS_OUT;
+                    } else {
+                        s.have = true;
+                        s.mode = use2 ? 2 : 1;
+                        s.sigma_mu = sigma_mu;
+                        s.alpha = alpha * fma(alpha, 0.9999999, (1.0 - alpha) * 0.99);
+                    }
+                }
+                if ((int)threadIdx.x == p) {
+                    state = n_state;
+                    if (n_status >= 0) status = n_status;
+                    qp_total += add_total;
+                    sqp_it += add_sqp;
+                    qp_it = qit;
+                    sp = s;
+                }
+            }
+            STAMP(11, state != LS_DONE);
+            continue;
+        }
 
         // ---- one interior-point iteration ---------------------------------------------------
         const bool st_c = (state == LS_QP);
