@@ -37,15 +37,31 @@ int fail(int code, const char *fmt, ...)
 
 constexpr int kWavesPerCU = 4;    // resident wavefronts per CU the kernel's register use admits
 
-// upper bound used to size workspaces without asking the device
-int waves_for(int B)
+// How a batch is spread over persistent wavefronts.  Large batches fill every wavefront
+// (64 problems each, refilled from the queue).  Small ones are spread thin, down to one
+// problem per wavefront, because a wavefront with few problems finishes each of them
+// sooner; the spread is limited so that the workspace stays below kWorkspaceTarget.
+struct Plan { int waves, lanes; };
+constexpr size_t kWorkspaceTarget = (size_t)8 << 30;
+
+Plan plan_for(int B, int N)
 {
-    int g = (B + 63) / 64;
-    return g < kMaxWaves ? g : kMaxWaves;
+    const size_t per_wave = (size_t)(N + 1) * mpcx_stage_doubles(MPCX_MAX_OBS) * 64 * sizeof(double);
+    size_t cap = kWorkspaceTarget / per_wave;
+    if (cap < 1) cap = 1;
+    if (cap > (size_t)kMaxWaves) cap = kMaxWaves;
+    Plan p;
+    p.lanes = (int)(((size_t)B + cap - 1) / cap);
+    if (p.lanes < 1) p.lanes = 1;
+    if (p.lanes > 64) p.lanes = 64;
+    p.waves = (B + p.lanes - 1) / p.lanes;
+    if (p.waves > (int)cap) p.waves = (int)cap;
+    if (p.waves < 1) p.waves = 1;
+    return p;
 }
 
 // persistent wavefronts actually launched on the current device
-int waves_to_launch(int B)
+int waves_to_launch(const Plan &p)
 {
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -53,9 +69,7 @@ int waves_to_launch(int B)
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     int w = cus * kWavesPerCU;
-    if (w > kMaxWaves) w = kMaxWaves;
-    int g = waves_for(B);
-    return g < w ? g : w;
+    return p.waves < w ? p.waves : w;
 }
 
 int check_call(const mpcx_batch *in, const mpcx_opts *o, const mpcx_result *out)
@@ -116,7 +130,7 @@ int mpcx_device_count(void)
 size_t mpcx_workspace_bytes(int32_t B, int32_t N)
 {
     if (B <= 0 || N < 1) return 0;
-    return 512 + (size_t)waves_for(B) * (size_t)(N + 1) * mpcx_stage_doubles(MPCX_MAX_OBS) * 64 * sizeof(double);
+    return 512 + (size_t)plan_for(B, N).waves * (size_t)(N + 1) * mpcx_stage_doubles(MPCX_MAX_OBS) * 64 * sizeof(double);
 }
 
 int mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *out,
@@ -126,12 +140,12 @@ int mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts, mpcx_re
     if (in->B == 0) return 0;
     if (mpcx_device_count() <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
     const int nh = (opts->max_obs < 0) ? MPCX_MAX_OBS : opts->max_obs;
-    const int n_waves = waves_for(in->B);
-    const size_t need = 512 + (size_t)n_waves * (size_t)(in->N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
+    const Plan plan = plan_for(in->B, in->N);
+    const size_t need = 512 + (size_t)plan.waves * (size_t)(in->N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
     if (!workspace || workspace_bytes < need)
         return fail(MPCX_E_BADARG, "workspace too small: %zu bytes given, %zu needed", workspace_bytes, need);
     if ((uintptr_t)workspace % 256 != 0) return fail(MPCX_E_BADARG, "workspace not 256-byte aligned");
-    HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(workspace), waves_to_launch(in->B),
+    HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(workspace), waves_to_launch(plan), plan.lanes,
                             static_cast<hipStream_t>(stream)));
     return 0;
 }
@@ -160,8 +174,8 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
 
     const size_t n_pd = (size_t)MPCX_NFIELDS * B, n_xg = (N + 1) * MPCX_NX * B;
     const size_t n_X = B * (N + 1) * MPCX_NX, n_U = B * N * MPCX_NU;
-    const int n_waves = waves_for(in->B);
-    const size_t ws_bytes = 512 + (size_t)n_waves * (N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
+    const Plan plan = plan_for(in->B, in->N);
+    const size_t ws_bytes = 512 + (size_t)plan.waves * (N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
 
     DevBuf d_pd, d_no, d_xg, d_X, d_U, d_st, d_si, d_qi, d_co, d_re, d_ws;
     if (d_pd.alloc(n_pd * 8) != hipSuccess || d_no.alloc(B * 4) != hipSuccess ||
@@ -192,7 +206,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     dout.cost = d_co.as<double>();
     dout.res = d_re.as<double>();
 
-    HIP_TRY(mpcx_launch_sqp(nh, din, o, dout, d_ws.as<double>(), waves_to_launch(in->B), nullptr));
+    HIP_TRY(mpcx_launch_sqp(nh, din, o, dout, d_ws.as<double>(), waves_to_launch(plan), plan.lanes, nullptr));
     HIP_TRY(hipDeviceSynchronize());
 
     HIP_TRY(hipMemcpy(out->X, d_X.p, n_X * 8, hipMemcpyDeviceToHost));

@@ -688,7 +688,6 @@ struct B0Out {
     double vx[NX], qpi[NX];
     double ng, nb, nd, nm, ssum;
 };
-constexpr int B0OUT_BCAST = NZ + NZ + 3 + NX + 14;      // leading doubles the Riccati part reads
 
 // store by the lanes that own the data: every lane in lane-per-problem mode, one lane
 // when the wavefront works on a single problem and all lanes hold the same value
@@ -1371,10 +1370,10 @@ __device__ __attribute__((noinline)) double sweep_F(Lane L, PC<NH> pc, const mpc
 // single-problem mode.  When a wavefront has only a few problems left (the end of
 // a batch, or a call with a handful of problems) one lane per problem leaves the
 // machine waiting on the memory latency of one dependency chain.  The sweeps
-// below work on ONE problem with lane j on stage j (N + 1 <= 64): the row part of
-// every stage runs at once, the recursion over the stages runs once, on values
-// broadcast from the lane that owns the stage, and the reductions visit the stages
-// in the order the one-lane-per-problem sweeps do.  Every number is produced by
+// below work on ONE problem, 64 consecutive stages at a time with lane j on the j-th
+// of them: the row part of the 64 stages runs at once, the recursion over them runs
+// once, on values broadcast from the lane that owns the stage, and the reductions
+// visit the stages in the order the one-lane-per-problem sweeps do.  Every number is produced by
 // the same operations in the same order, so which mode ran leaves no trace in
 // the results.
 // ---------------------------------------------------------------------------
@@ -1420,7 +1419,7 @@ DEV Lane stage_lane(const Lane &C, unsigned j, bool writer)
     return S;
 }
 
-template <int NH>
+template <int NH, bool ONE>
 __device__ __attribute__((noinline)) void coop_B0(Lane C, PC<NH> pc, const mpcx_opts *op, bool sp_have, int sp_mode,
                                                   double sp_sigma_mu, double sp_alpha, int m_total, ldouble *ret)
 {
@@ -1429,147 +1428,176 @@ __device__ __attribute__((noinline)) void coop_B0(Lane C, PC<NH> pc, const mpcx_
     sp.have = sp_have; sp.mode = sp_mode; sp.sigma_mu = sp_sigma_mu; sp.alpha = sp_alpha;
     const int N = C.N;
     const int j = (int)threadIdx.x;
-    const Lane S = stage_lane(C, (unsigned)j, true);
     coop_sync();
-    // the stage above supplies its updated state and multiplier
-    double vx[NX], qpi[NX], vxn[NX], qpin[NX];
+    double Pn[15], pn[NX], cvx[NX], cqpi[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { vx[i] = 0.0; qpi[i] = 0.0; }
-    if (j <= N) stage_B0_peek<NH>(S, 0, sp, vx, qpi);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { vxn[i] = from_next_lane(vx[i]); qpin[i] = from_next_lane(qpi[i]); }
-    B0Out t = {};
-    if (j == 0) stage_B0_rows<NH, FIRST>(S, o, pc, 0, sp, vxn, qpin, t);
-    else if (j < N) stage_B0_rows<NH, MID>(S, o, pc, 0, sp, vxn, qpin, t);
-    else if (j == N) stage_B0_rows<NH, LAST>(S, o, pc, 0, sp, vxn, qpin, t);
-    // recursion and reductions, stage N down to 0
-    double Pn[15], pn[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) pn[i] = 0.0;
+    for (int i = 0; i < NX; ++i) { pn[i] = 0.0; cvx[i] = 0.0; cqpi[i] = 0.0; }
 #pragma unroll
     for (int i = 0; i < 15; ++i) Pn[i] = 0.0;
     double ng = 0.0, nb = 0.0, nd = 0.0, nm = 0.0, sum = 0.0;
-    for (int k = N; k >= 0; --k) {
-        B0Out in;
+    // blocks of 64 consecutive stages, the last block first (ONE: N < 64, a single block)
+    for (int k0 = ONE ? 0 : (N / 64) * 64; k0 >= 0; k0 -= 64) {
+        const int kj = k0 + j;
+        const Lane S = stage_lane(C, (unsigned)kj, true);
+        // the stage above supplies its updated state and multiplier: the next lane, or the
+        // first stage of the block before (cvx, cqpi)
+        double vx[NX], qpi[NX], vxn[NX], qpin[NX];
 #pragma unroll
-        for (int i = 0; i < NZ; ++i) { in.gt[i] = bcast(t.gt[i], k); in.Ht[i] = bcast(t.Ht[i], k); }
-        in.hxx = bcast(t.hxx, k); in.hxy = bcast(t.hxy, k); in.hyy = bcast(t.hyy, k);
+        for (int i = 0; i < NX; ++i) { vx[i] = 0.0; qpi[i] = 0.0; }
+        if (kj <= N) stage_B0_peek<NH>(S, 0, sp, vx, qpi);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) in.rb[i] = bcast(t.rb[i], k);
-        in.ab = bcast_ab(t.ab, k);
-        ng = dmax(ng, bcast(t.ng, k)); nb = dmax(nb, bcast(t.nb, k));
-        nd = dmax(nd, bcast(t.nd, k)); nm = dmax(nm, bcast(t.nm, k));
-        sum = sum + bcast(t.ssum, k);
-        const Lane R = stage_lane(C, (unsigned)k, j == 0);
-        // (stage 0 also stores its P, into a slot nobody reads)
-        if (k == N) stage_B0_ric<NH, LAST, true>(R, 0, in, Pn, pn);
-        else stage_B0_ric<NH, MID, true>(R, 0, in, Pn, pn);
+        for (int i = 0; i < NX; ++i) {
+            const double a = from_next_lane(vx[i]), b = from_next_lane(qpi[i]);
+            vxn[i] = (j == 63) ? cvx[i] : a;
+            qpin[i] = (j == 63) ? cqpi[i] : b;
+            cvx[i] = bcast(vx[i], 0);
+            cqpi[i] = bcast(qpi[i], 0);
+        }
+        B0Out t = {};
+        if (kj == 0) stage_B0_rows<NH, FIRST>(S, o, pc, 0, sp, vxn, qpin, t);
+        else if (kj < N) stage_B0_rows<NH, MID>(S, o, pc, 0, sp, vxn, qpin, t);
+        else if (kj == N) stage_B0_rows<NH, LAST>(S, o, pc, 0, sp, vxn, qpin, t);
+        // recursion and reductions over the stages of the block, downwards
+        const int kend = (N - k0 < 63) ? N - k0 : 63;
+        for (int kk = kend; kk >= 0; --kk) {
+            B0Out in;
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) { in.gt[i] = bcast(t.gt[i], kk); in.Ht[i] = bcast(t.Ht[i], kk); }
+            in.hxx = bcast(t.hxx, kk); in.hxy = bcast(t.hxy, kk); in.hyy = bcast(t.hyy, kk);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) in.rb[i] = bcast(t.rb[i], kk);
+            in.ab = bcast_ab(t.ab, kk);
+            ng = dmax(ng, bcast(t.ng, kk)); nb = dmax(nb, bcast(t.nb, kk));
+            nd = dmax(nd, bcast(t.nd, kk)); nm = dmax(nm, bcast(t.nm, kk));
+            sum = sum + bcast(t.ssum, kk);
+            const Lane R = stage_lane(C, (unsigned)(k0 + kk), j == 0);
+            // (stage 0 also stores its P, into a slot nobody reads)
+            if (k0 + kk == N) stage_B0_ric<NH, LAST, true>(R, 0, in, Pn, pn);
+            else stage_B0_ric<NH, MID, true>(R, 0, in, Pn, pn);
+        }
     }
     coop_sync();
     ret[0 * 64] = ng; ret[1 * 64] = nb; ret[2 * 64] = nd; ret[3 * 64] = nm;
     ret[4 * 64] = sum / (double)m_total;
 }
 
-template <int NH>
+template <int NH, bool ONE>
 __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_opts *op, double sigma_mu)
 {
     const mpcx_opts &o = *op;
     const int N = C.N;
     const int j = (int)threadIdx.x;
-    const Lane S = stage_lane(C, (unsigned)j, true);
     coop_sync();
-    BsOut t = {};
-    if (j == 0) stage_Bs_rows<NH, FIRST>(S, o, pc, 0, sigma_mu, t);
-    else if (j < N) stage_Bs_rows<NH, MID>(S, o, pc, 0, sigma_mu, t);
-    else if (j == N) stage_Bs_rows<NH, LAST>(S, o, pc, 0, sigma_mu, t);
     double pn1[NX], pn2[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) { pn1[i] = 0.0; pn2[i] = 0.0; }
-    for (int k = N; k >= 0; --k) {
-        BsOut in;
+    for (int k0 = ONE ? 0 : (N / 64) * 64; k0 >= 0; k0 -= 64) {
+        const int kj = k0 + j;
+        const Lane S = stage_lane(C, (unsigned)kj, true);
+        BsOut t = {};
+        if (kj == 0) stage_Bs_rows<NH, FIRST>(S, o, pc, 0, sigma_mu, t);
+        else if (kj < N) stage_Bs_rows<NH, MID>(S, o, pc, 0, sigma_mu, t);
+        else if (kj == N) stage_Bs_rows<NH, LAST>(S, o, pc, 0, sigma_mu, t);
+        const int kend = (N - k0 < 63) ? N - k0 : 63;
+        for (int kk = kend; kk >= 0; --kk) {
+            BsOut in;
 #pragma unroll
-        for (int i = 0; i < NZ; ++i) { in.gt1[i] = bcast(t.gt1[i], k); in.gt2[i] = bcast(t.gt2[i], k); }
+            for (int i = 0; i < NZ; ++i) { in.gt1[i] = bcast(t.gt1[i], kk); in.gt2[i] = bcast(t.gt2[i], kk); }
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            in.prb[i] = bcast(t.prb[i], k); in.k0[i] = bcast(t.k0[i], k); in.k1[i] = bcast(t.k1[i], k);
+            for (int i = 0; i < NX; ++i) {
+                in.prb[i] = bcast(t.prb[i], kk); in.k0[i] = bcast(t.k0[i], kk); in.k1[i] = bcast(t.k1[i], kk);
+            }
+            in.l10 = bcast(t.l10, kk); in.d0 = bcast(t.d0, kk); in.d1 = bcast(t.d1, kk);
+            in.ab = bcast_ab(t.ab, kk);
+            const int k = k0 + kk;
+            const Lane R = stage_lane(C, (unsigned)k, j == 0);
+            if (k == N) stage_Bs_rec<NH, LAST, true>(R, 0, in, pn1, pn2);
+            else if (k > 0) stage_Bs_rec<NH, MID, true>(R, 0, in, pn1, pn2);
+            else stage_Bs_rec<NH, FIRST, true>(R, 0, in, pn1, pn2);
         }
-        in.l10 = bcast(t.l10, k); in.d0 = bcast(t.d0, k); in.d1 = bcast(t.d1, k);
-        in.ab = bcast_ab(t.ab, k);
-        const Lane R = stage_lane(C, (unsigned)k, j == 0);
-        if (k == N) stage_Bs_rec<NH, LAST, true>(R, 0, in, pn1, pn2);
-        else if (k > 0) stage_Bs_rec<NH, MID, true>(R, 0, in, pn1, pn2);
-        else stage_Bs_rec<NH, FIRST, true>(R, 0, in, pn1, pn2);
     }
     coop_sync();
 }
 
-template <int NH, int NS>
+template <int NH, int NS, bool ONE>
 __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx_opts *op, double sigma_mu, ldouble *ret)
 {
     typedef Map<NH> M;
     const mpcx_opts &o = *op;
     const int N = C.N;
     const int j = (int)threadIdx.x;
-    const Lane S = stage_lane(C, (unsigned)j, true);
     coop_sync();
-    // what the recursion needs of every stage
-    AB ab = {};
-    double rb[NX], kg[NU][NX], kv[NS][NU];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { rb[i] = 0.0; kg[0][i] = 0.0; kg[1][i] = 0.0; }
-#pragma unroll
-    for (int q = 0; q < NS; ++q) { kv[q][0] = 0.0; kv[q][1] = 0.0; }
-    if (j < N) {
-        load_ab<NH>(S, 0, ab);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            rb[i] = ldw(S, 0, M::RB + i);
-            kg[0][i] = ldw(S, 0, M::K + i);
-            kg[1][i] = ldw(S, 0, M::K + NX + i);
-        }
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            kv[q][0] = ldw(S, 0, M::KV + q * M::SOL2 + 0);
-            kv[q][1] = ldw(S, 0, M::KV + q * M::SOL2 + 1);
-        }
-    }
-    // the state step of every stage, kept by the lane of the stage
-    double dx[NS][NX], mydx[NS][NX];
+    double dx[NS][NX];           // state step entering the stage the recursion stands at
 #pragma unroll
     for (int q = 0; q < NS; ++q)
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { dx[q][i] = 0.0; mydx[q][i] = 0.0; }
-    for (int k = 0; k < N; ++k) {
-        const AB abk = bcast_ab(ab, k);
-        double rbk[NX], kgk[NU][NX];
+        for (int i = 0; i < NX; ++i) dx[q][i] = 0.0;
+    double alpha[2] = {1.0, 1.0}, s1 = 0.0, s2 = 0.0;
+    for (int k0 = 0; ONE ? (k0 == 0) : (k0 <= N); k0 += 64) {
+        const int kj = k0 + j;
+        const Lane S = stage_lane(C, (unsigned)kj, true);
+        // what the recursion needs of every stage of the block
+        AB ab = {};
+        double rb[NX], kg[NU][NX], kv[NS][NU];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            rbk[i] = bcast(rb[i], k); kgk[0][i] = bcast(kg[0][i], k); kgk[1][i] = bcast(kg[1][i], k);
-        }
+        for (int i = 0; i < NX; ++i) { rb[i] = 0.0; kg[0][i] = 0.0; kg[1][i] = 0.0; }
 #pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            const double kvk[NU] = {bcast(kv[q][0], k), bcast(kv[q][1], k)};
-            double du[NU], dxn[NX];
-            F_rec(C, abk, kgk, kvk, rbk, dx[q], du, dxn);
+        for (int q = 0; q < NS; ++q) { kv[q][0] = 0.0; kv[q][1] = 0.0; }
+        if (kj < N) {
+            load_ab<NH>(S, 0, ab);
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                dx[q][i] = dxn[i];
-                mydx[q][i] = (j == k + 1) ? dxn[i] : mydx[q][i];
+                rb[i] = ldw(S, 0, M::RB + i);
+                kg[0][i] = ldw(S, 0, M::K + i);
+                kg[1][i] = ldw(S, 0, M::K + NX + i);
+            }
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                kv[q][0] = ldw(S, 0, M::KV + q * M::SOL2 + 0);
+                kv[q][1] = ldw(S, 0, M::KV + q * M::SOL2 + 1);
             }
         }
-    }
-    FAcc a = {{1.0, 1.0}, 0.0, 0.0};
-    if (j == 0) stage_F<NH, FIRST, NS>(S, o, pc, 0, sigma_mu, mydx, a);
-    else if (j < N) stage_F<NH, MID, NS>(S, o, pc, 0, sigma_mu, mydx, a);
-    else if (j == N) stage_F<NH, LAST, NS>(S, o, pc, 0, sigma_mu, mydx, a);
-    double alpha[2] = {1.0, 1.0}, s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k <= N; ++k) {
+        // the recursion; the lane of a stage keeps the state step that enters it
+        double mydx[NS][NX];
 #pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            const double ak = bcast(a.alpha[q], k);
-            alpha[q] = (ak < alpha[q]) ? ak : alpha[q];
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+            for (int i = 0; i < NX; ++i) mydx[q][i] = 0.0;
+        const int kend = (N - k0 < 63) ? N - k0 : 63;
+        for (int kk = 0; kk <= kend; ++kk) {
+#pragma unroll
+            for (int q = 0; q < NS; ++q)
+#pragma unroll
+                for (int i = 0; i < NX; ++i) mydx[q][i] = (j == kk) ? dx[q][i] : mydx[q][i];
+            if (k0 + kk < N) {
+                const AB abk = bcast_ab(ab, kk);
+                double rbk[NX], kgk[NU][NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    rbk[i] = bcast(rb[i], kk); kgk[0][i] = bcast(kg[0][i], kk); kgk[1][i] = bcast(kg[1][i], kk);
+                }
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    const double kvk[NU] = {bcast(kv[q][0], kk), bcast(kv[q][1], kk)};
+                    double du[NU], dxn[NX];
+                    F_rec(C, abk, kgk, kvk, rbk, dx[q], du, dxn);
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) dx[q][i] = dxn[i];
+                }
+            }
         }
-        if (NS == 1) { s1 = s1 + bcast(a.s1, k); s2 = s2 + bcast(a.s2, k); }
+        FAcc a = {{1.0, 1.0}, 0.0, 0.0};
+        if (kj == 0) stage_F<NH, FIRST, NS>(S, o, pc, 0, sigma_mu, mydx, a);
+        else if (kj < N) stage_F<NH, MID, NS>(S, o, pc, 0, sigma_mu, mydx, a);
+        else if (kj == N) stage_F<NH, LAST, NS>(S, o, pc, 0, sigma_mu, mydx, a);
+        for (int kk = 0; kk <= kend; ++kk) {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const double ak = bcast(a.alpha[q], kk);
+                alpha[q] = (ak < alpha[q]) ? ak : alpha[q];
+            }
+            if (NS == 1) { s1 = s1 + bcast(a.s1, kk); s2 = s2 + bcast(a.s2, kk); }
+        }
     }
     coop_sync();
     if (NS == 1) { ret[0 * 64] = s1; ret[1 * 64] = s2; }
@@ -1589,7 +1617,7 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
 // of the tick loop, read back by mpcx_debug_read_stamps().  No stamp code is
 // compiled into the shipped library.
 #ifdef MPCX_STAMPS
-#define N_STAMP 24
+#define N_STAMP 32
 __device__ unsigned long long g_stamps[2048][N_STAMP];
 #define STAMP_BEGIN() unsigned long long st_t0 = __builtin_amdgcn_s_memtime()
 #define STAMP(slot, pred)                                                              \
@@ -1628,7 +1656,7 @@ enum LaneState {
 
 template <int NH>
 __global__ void __launch_bounds__(64)
-mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter)
+mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes)
 {
     const mpcx_opts &o = *op;
     typedef Map<NH> M;
@@ -1654,7 +1682,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     L.nobs = 0;
     L.h = L.hh = L.h6 = L.hB = L.invL = 0.0;
 
-    int state = LS_FETCH;
+    int state = ((int)threadIdx.x < lanes) ? LS_FETCH : LS_DONE;
     int status = MPCX_MAXITER, sqp_it = 0, qp_it = 0, qp_total = 0, m_total = 0;
     bool first = true;
     double res[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1668,7 +1696,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         const bool wants = (state == LS_OUT) || (state == LS_FETCH) || (state == LS_LIN);
         const int n_wants = __popcll(__ballot(wants));
         const int n_qp = __popcll(__ballot(state == LS_QP));
-        const bool few = (N < 64) && (n_qp <= MPCX_COOP_MAX);     // single-problem mode ahead
+        const bool few = n_qp <= MPCX_COOP_MAX;     // single-problem mode ahead
         if (n_wants >= MPCX_SERVICE_MIN || n_qp == 0 || (few && n_wants > 0)) {
             const bool st_e = (state == LS_OUT);
             if (state == LS_OUT) {
@@ -1771,7 +1799,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
 
         // ---- few problems left: one interior-point iteration of each, the wavefront on one problem
         const unsigned long long qp_mask = __ballot(state == LS_QP);
-        if ((N < 64) && __popcll(qp_mask) <= MPCX_COOP_MAX) {
+        if (__popcll(qp_mask) <= MPCX_COOP_MAX) {
             for (unsigned long long rest = qp_mask; rest != 0; rest &= rest - 1) {
                 const int p = __ffsll((long long)rest) - 1;
                 Lane C = L;
@@ -1791,7 +1819,9 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                 const int mt = __builtin_amdgcn_readlane(m_total, p);
                 int qit = __builtin_amdgcn_readlane(qp_it, p);
                 int n_state = LS_QP, n_status = -1, add_total = 0, add_sqp = 0;
-                coop_B0<NH>(C, pcc, op, s.have, s.mode, s.sigma_mu, s.alpha, mt, ret);
+                if (N < 64) coop_B0<NH, true>(C, pcc, op, s.have, s.mode, s.sigma_mu, s.alpha, mt, ret);
+                else coop_B0<NH, false>(C, pcc, op, s.have, s.mode, s.sigma_mu, s.alpha, mt, ret);
+                STAMP(12, true);
                 const double Rg = uniform(ret[0 * 64]), Rb = uniform(ret[1 * 64]), Rd = uniform(ret[2 * 64]),
                              Rm = uniform(ret[3 * 64]), mu = uniform(ret[4 * 64]);
                 int qs = -1;
@@ -1804,7 +1834,9 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                     if (qs == 3) { n_status = MPCX_QP_FAILURE; n_state = LS_OUT; }
                     else n_state = LS_LIN;
                 } else {
-                    const double a_aff = uniform(coop_F<NH, 1>(C, pcc, op, 0.0, ret));
+                    const double a_aff = uniform((N < 64) ? coop_F<NH, 1, true>(C, pcc, op, 0.0, ret)
+                                                          : coop_F<NH, 1, false>(C, pcc, op, 0.0, ret));
+                    STAMP(13, true);
                     const double S1 = uniform(ret[0 * 64]), S2 = uniform(ret[1 * 64]);
                     double S0 = mu * (double)mt;
                     double mu_aff = fma(a_aff, fma(a_aff, S2, S1), S0) / (double)mt;
@@ -1812,9 +1844,13 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                     double ratio = mu_aff / mu;
                     double sigma = ratio * ratio * ratio;
                     const double sigma_mu = sigma * mu;
-                    coop_Bs<NH>(C, pcc, op, sigma_mu);
-                    const double alpha1 = uniform(coop_F<NH, 2>(C, pcc, op, sigma_mu, ret));
+                    if (N < 64) coop_Bs<NH, true>(C, pcc, op, sigma_mu);
+                    else coop_Bs<NH, false>(C, pcc, op, sigma_mu);
+                    STAMP(14, true);
+                    const double alpha1 = uniform((N < 64) ? coop_F<NH, 2, true>(C, pcc, op, sigma_mu, ret)
+                                                           : coop_F<NH, 2, false>(C, pcc, op, sigma_mu, ret));
                     const double alpha2 = uniform(ret[0 * 64]);
+                    STAMP(15, true);
                     const bool use2 = o.cond_pred_corr && (alpha1 < a_aff);
                     const double alpha = use2 ? alpha2 : alpha1;
                     ++qit;
@@ -1927,8 +1963,9 @@ size_t mpcx_stage_doubles(int nh)
 }
 
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
-                           double *workspace, int n_waves, hipStream_t stream)
+                           double *workspace, int n_waves, int lanes, hipStream_t stream)
 {
+    if (lanes < 1 || lanes > 64 || n_waves < 1) return hipErrorInvalidValue;
     // workspace header (512 bytes): problem counter at byte 0, the options at byte 256
     static_assert(sizeof(mpcx_opts) <= 256, "options must fit the workspace header");
     int *counter = reinterpret_cast<int *>(workspace);
@@ -1941,12 +1978,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     if (e != hipSuccess) return e;
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes); break;
 #else
     default: return hipErrorInvalidValue;
 #endif

@@ -17,18 +17,22 @@ from mpc_amd import _lib  # noqa: E402
 from mpc_amd.synthetic import synthetic_batch  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+ONLY = int(sys.argv[2]) if len(sys.argv) > 2 else -1        # solve just this problem of the batch
 lib = _lib.load_library(os.path.join(ROOT, "mpc_amd", "csrc", "libmpcx_stamps.so"))
 _lib._lib = lib
 packed = synthetic_batch(B)
+if ONLY >= 0:
+    packed = packed.slice(ONLY, ONLY + 1)
 t0 = time.time()
 out = _lib.solve_packed(packed)
 dt = time.time() - t0
-NS = 24
+NS = 32
 buf = np.zeros((2048, NS), dtype=np.uint64)
 lib.mpcx_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.mpcx_debug_read_stamps(buf.ctypes.data, 1) == 0
 names = ["A fetch+init", "B sweep L", "sweep B0", "sweep F (affine)", "sweep Bs (both rhs)", "sweep F (both steps)",
-         "-", "-", "E write-out", "busy lanes", "ticks*64"]
+         "-", "-", "E write-out", "busy lanes", "ticks*64", "single-problem ticks", "  single B0", "  single F (affine)",
+         "  single Bs", "  single F (both)"]
 cyc = buf[:, 0::2].astype(np.float64)
 cnt = buf[:, 1::2].astype(np.float64)
 used = cyc.sum(1) > 0
@@ -37,8 +41,8 @@ tot = cyc[used].sum()
 ticks = None
 for i, n in enumerate(names):
     c = cyc[used, i].sum()
-    print(f"{n:14s} share {100 * c / tot:5.1f}%   lanes-sum {cnt[used, i].sum():.3g}")
-print("cycles per wave (mean) %.3g  (100 MHz ticks => %.3f s)" % (cyc[used].sum(1).mean(), cyc[used].sum(1).mean() / 1e8))
+    print(f"{n:22s} share {100 * c / tot:5.1f}%   cycles {c:.4g}  lanes-sum {cnt[used, i].sum():.3g}")
+print("cycles per wave (mean) %.3g" % cyc[used].sum(1).mean())
 w = cyc[used].sum(1)
 print("cycles per wave: min %.3g median %.3g p90 %.3g max %.3g" % (w.min(), np.median(w), np.percentile(w, 90), w.max()))
 print("qp_iter sum", int(out["qp_iter"].sum()), "sqp_iter sum", int(out["sqp_iter"].sum()))
