@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -52,6 +53,12 @@ Plan plan_for(int B, int N)
     if (cap > (size_t)kMaxWaves) cap = kMaxWaves;
     Plan p;
     p.lanes = (int)(((size_t)B + cap - 1) / cap);
+    // diagnostic knob: MPCX_LANES=n fixes the problems per wavefront (tests use it to run
+    // small batches through the one-lane-per-problem sweeps)
+    if (const char *e = std::getenv("MPCX_LANES")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 64) p.lanes = v;
+    }
     if (p.lanes < 1) p.lanes = 1;
     if (p.lanes > 64) p.lanes = 64;
     p.waves = (B + p.lanes - 1) / p.lanes;

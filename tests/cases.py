@@ -79,3 +79,31 @@ def assert_same_solution(gpu, ref, what=""):
                                  f"elements differ, max abs diff {diff:.3e}")
     a, b = gpu["res"][:, ok], ref["res"][:, ok]
     assert ((a == b) | (np.isnan(a) & np.isnan(b))).all(), f"{what}: residuals differ"
+
+
+def obstacle_problems(B, duration, seed=5):
+    """Random start/goal pairs with one or two obstacles near the straight path (a synthetic
+    mix: the reference's only obstacle case is the path_finder demo above)."""
+    rng = np.random.default_rng(seed)
+    sim = SimConfig()
+    sim.duration = duration
+    egos = []
+    for b in range(B):
+        e = EgoConfig()
+        s = np.array([rng.uniform(-20, 20), rng.uniform(-20, 20), rng.uniform(-1.5, 1.5), rng.uniform(0, 1), 0.0])
+        d = rng.uniform(0.4, 0.9) * 2.0 * duration
+        phi = s[2] + rng.uniform(-0.5, 0.5)
+        g = np.array([s[0] + d * np.cos(phi), s[1] + d * np.sin(phi), phi + rng.uniform(-0.4, 0.4),
+                      rng.uniform(0, 1), 0.0])
+        e.state_start = list(s)
+        e.state_final = list(g)
+        obs = []
+        for j in range(1 + b % 2):
+            t = rng.uniform(0.3, 0.7)
+            off = rng.choice([-1.0, 1.0]) * rng.uniform(0.5, 2.0)
+            obs.append([s[0] + t * (g[0] - s[0]) - off * np.sin(phi), s[1] + t * (g[1] - s[1]) + off * np.cos(phi),
+                        1.0, 0.5])
+        e.obstacles = obs if b % 3 else None
+        e.verbose = False
+        egos.append(e)
+    return egos, sim

@@ -43,7 +43,7 @@ def test_sincos_bits(oracle):
         assert (c[i] == co.value or (np.isnan(c[i]) and np.isnan(co.value))), (x[i], c[i], co.value)
 
 
-@pytest.mark.parametrize("B", [1, 63, 64, 65, 1000])
+@pytest.mark.parametrize("B", [1, 63, 64, 65, 1000, 20000])
 def test_synthetic_batch_matches_oracle(oracle, B):
     packed = synthetic_batch(B)
     gpu = _lib.solve_packed(packed)
@@ -89,3 +89,18 @@ def test_failures_match_oracle(oracle):
     ref = oracle.solve_packed(packed)
     cases.assert_same_solution(gpu, ref, "infeasible batch")
     assert (ref["status"] != 0).all()
+
+
+@pytest.mark.parametrize("duration", [0.2, 5.0, 6.35, 6.4, 6.5, 13.0])
+@pytest.mark.parametrize("lanes", [1, 3, 64])
+def test_sweep_modes_match_oracle(oracle, monkeypatch, duration, lanes):
+    """The same problems through the one-lane-per-problem sweeps (64 per wavefront) and
+    through the single-problem sweeps (1 or 3 per wavefront), horizons around the 64-stage
+    block size (N = 2, 50, 63, 64, 65, 130), obstacle rows included."""
+    egos, sim = cases.obstacle_problems(96, duration)
+    packed = pack_problems(egos, sim)
+    assert packed.N == int(duration / 0.1)
+    monkeypatch.setenv("MPCX_LANES", str(lanes))
+    gpu = _lib.solve_packed(packed)
+    ref = oracle.solve_packed(packed)
+    cases.assert_same_solution(gpu, ref, f"N={packed.N} lanes={lanes}")
