@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1_000_000, help="problems per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=16384, help="problems timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=262144, help="problems timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -130,6 +130,15 @@ def main():
     steps = max(args.steps, 1)
     value = n_conv_all * steps / elapsed
     achieved_tf = fl / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    # HBM bytes of one launch from the committed counter passes (same batch only)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        if int(pmc["batch"]) == B:
+            traffic = (float(pmc["fetch_kib"]) + float(pmc["write_kib"])) * 1024.0
+    except (OSError, ValueError, KeyError):
+        pass
     io_bytes = flops.algorithmic_io_bytes(N) * B
     line = {
         "metric": "converged OCPs/sec (N=50 kinematic car)",
@@ -145,7 +154,7 @@ def main():
                    "parallelism": f"independent batch slice per GPU x{world}"},
         "roofline": {"bound": "valu_fp64", "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS,
-                     "traffic": None,
+                     "traffic": traffic,
                      "kernel": "mpcx_sqp_kernel<0>", "kernel_ms": kernel_ms,
                      "algorithmic_flops_per_launch": fl,
                      "batch_io_GBs": io_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0},
