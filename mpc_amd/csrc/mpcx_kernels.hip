@@ -689,15 +689,6 @@ struct B0Out {
     double ng, nb, nd, nm, ssum;
 };
 
-// store by the lanes that own the data: every lane in lane-per-problem mode, one lane
-// when the wavefront works on a single problem and all lanes hold the same value
-template <bool COOP>
-DEV void stwc(const Lane &L, int k, int f, double v)
-{
-    if (!COOP) stw(L, k, f, v);
-    else if (L.writer) stw(L, k, f, v);
-}
-
 // B0, row part of stage k: applies the pending step to the stage's iterate, then residuals,
 // barrier Hessian and affine right-hand side.  vxn / qpin: updated x-part of v and dynamics
 // multiplier of stage k+1.
@@ -892,10 +883,11 @@ DEV void stage_B0_peek(const Lane &L, int k, const Step &sp, double *vx, double 
 
 // B0, Riccati part of stage k: factorisation and backward substitution of the affine
 // right-hand side; Pn, pn hold P(k+1), p(k+1) on entry and P(k), p(k) on return
-template <int NH, int KIND, bool COOP>
-DEV void stage_B0_ric(const Lane &L, int k, const B0Out &in, double *Pn, double *pn)
+struct RicOut { double prb[NX], l10, d0, d1, K[NU][NX], kv[NU]; };
+
+template <int KIND>
+DEV void stage_B0_ric(const Lane &L, const B0Out &in, double *Pn, double *pn, RicOut &ro)
 {
-    typedef Map<NH> M;
     if (KIND == LAST) {
         // P_N = barrier Hessian of the terminal state, p_N = its right-hand side
 #pragma unroll
@@ -917,7 +909,7 @@ DEV void stage_B0_ric(const Lane &L, int k, const B0Out &in, double *Pn, double 
             double acc = psym(Pn, i, 0) * in.rb[0];
 #pragma unroll
             for (int j = 1; j < NX; ++j) acc = fma(psym(Pn, i, j), in.rb[j], acc);
-            stwc<COOP>(L, k, M::PRB + i, acc);
+            ro.prb[i] = acc;
             w[i] = pn[i] + acc;
         }
         // PBA = P(k+1) [B A]; columns 0,1 = B, 2..6 = A
@@ -958,9 +950,7 @@ DEV void stage_B0_ric(const Lane &L, int k, const B0Out &in, double *Pn, double 
         const double d0 = 1.0 / Mm[0][0];                          // reciprocal pivots
         const double l10 = Mm[1][0] * d0;
         const double d1 = 1.0 / fma(-l10, Mm[1][0], Mm[1][1]);
-        stwc<COOP>(L, k, M::LDL + 0, l10);
-        stwc<COOP>(L, k, M::LDL + 1, d0);
-        stwc<COOP>(L, k, M::LDL + 2, d1);
+        ro.l10 = l10; ro.d0 = d0; ro.d1 = d1;
         double Kg[NU][NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -970,8 +960,8 @@ DEV void stage_B0_ric(const Lane &L, int k, const B0Out &in, double *Pn, double 
             double s0 = fma(-l10, z1, z0);
             Kg[0][i] = -s0;
             Kg[1][i] = -z1;
-            stwc<COOP>(L, k, M::K + i, Kg[0][i]);
-            stwc<COOP>(L, k, M::K + NX + i, Kg[1][i]);
+            ro.K[0][i] = Kg[0][i];
+            ro.K[1][i] = Kg[1][i];
         }
         // right-hand side of this stage and feed-forward
         double m[NZ];
@@ -983,8 +973,8 @@ DEV void stage_B0_ric(const Lane &L, int k, const B0Out &in, double *Pn, double 
             double y1 = fma(-l10, y0, m[1]);
             double z0 = y0 * d0, z1 = y1 * d1;
             double s0 = fma(-l10, z1, z0);
-            stwc<COOP>(L, k, M::KV + 0, -s0);
-            stwc<COOP>(L, k, M::KV + 1, -z1);
+            ro.kv[0] = -s0;
+            ro.kv[1] = -z1;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) pn[i] = fma(Kg[1][i], m[1], fma(Kg[0][i], m[0], m[NU + i]));
@@ -997,9 +987,29 @@ DEV void stage_B0_ric(const Lane &L, int k, const B0Out &in, double *Pn, double 
                 Pn[tri(i, j)] = fma(Mm[NU + i][1], Kg[1][j], e);
             }
     }
-    if (KIND != FIRST) {
+}
+
+// the factors of stage k and its cost-to-go Hessian go to the workspace
+template <int NH>
+DEV void store_ric(const Lane &L, int k, bool factors, bool hessian, const RicOut &ro, const double *Pn)
+{
+    typedef Map<NH> M;
+    if (factors) {
 #pragma unroll
-        for (int i = 0; i < 15; ++i) stwc<COOP>(L, k, M::P + i, Pn[i]);
+        for (int i = 0; i < NX; ++i) {
+            stw(L, k, M::PRB + i, ro.prb[i]);
+            stw(L, k, M::K + i, ro.K[0][i]);
+            stw(L, k, M::K + NX + i, ro.K[1][i]);
+        }
+        stw(L, k, M::LDL + 0, ro.l10);
+        stw(L, k, M::LDL + 1, ro.d0);
+        stw(L, k, M::LDL + 2, ro.d1);
+        stw(L, k, M::KV + 0, ro.kv[0]);
+        stw(L, k, M::KV + 1, ro.kv[1]);
+    }
+    if (hessian) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) stw(L, k, M::P + i, Pn[i]);
     }
 }
 
@@ -1021,7 +1031,9 @@ __device__ __attribute__((noinline)) void sweep_B0(Lane L, PC<NH> pc, const mpcx
     {                                                                                  \
         B0Out t;                                                                       \
         stage_B0_rows<NH, KIND>(L, o, pc, kk, sp, vxn, qpin, t);                       \
-        stage_B0_ric<NH, KIND, false>(L, kk, t, Pn, pn);                               \
+        RicOut ro;                                                                     \
+        stage_B0_ric<KIND>(L, t, Pn, pn, ro);                                          \
+        store_ric<NH>(L, kk, KIND != LAST, KIND != FIRST, ro, Pn);                     \
         ng = dmax(ng, t.ng); nb = dmax(nb, t.nb); nd = dmax(nd, t.nd); nm = dmax(nm, t.nm); \
         sum = sum + t.ssum;                                                            \
         _Pragma("unroll") for (int i = 0; i < NX; ++i) { vxn[i] = t.vx[i]; qpin[i] = t.qpi[i]; } \
@@ -1118,11 +1130,11 @@ DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
     }
 }
 
-// Bs, recursion part of stage k: pn1 / pn2 hold p(k+1) of the two systems on entry, p(k) on return
-template <int NH, int KIND, bool COOP>
-DEV void stage_Bs_rec(const Lane &L, int k, const BsOut &in, double *pn1, double *pn2)
+// Bs, recursion part of a stage: pn1 / pn2 hold p(k+1) of the two systems on entry, p(k) on
+// return; kvo[s] = feed-forward of system s
+template <int KIND>
+DEV void stage_Bs_rec(const Lane &L, const BsOut &in, double *pn1, double *pn2, double (*kvo)[NU])
 {
-    typedef Map<NH> M;
     if (KIND == LAST) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) { pn1[i] = in.gt1[NU + i]; pn2[i] = in.gt2[NU + i]; }
@@ -1141,18 +1153,27 @@ DEV void stage_Bs_rec(const Lane &L, int k, const BsOut &in, double *pn1, double
             double y1 = fma(-in.l10, y0, m[1]);
             double z0 = y0 * in.d0, z1 = y1 * in.d1;
             double s0 = fma(-in.l10, z1, z0);
-            stwc<COOP>(L, k, (sidx ? M::KV2 : M::KV) + 0, -s0);
-            stwc<COOP>(L, k, (sidx ? M::KV2 : M::KV) + 1, -z1);
+            kvo[sidx][0] = -s0;
+            kvo[sidx][1] = -z1;
 #pragma unroll
             for (int i = 0; i < NX; ++i) pn[i] = fma(in.k1[i], m[1], fma(in.k0[i], m[0], m[NU + i]));
         }
     }
-    if (KIND != FIRST) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { stwc<COOP>(L, k, M::PV + i, pn1[i]); stwc<COOP>(L, k, M::PV2 + i, pn2[i]); }
-    }
 }
 
+template <int NH>
+DEV void store_rec(const Lane &L, int k, bool ff, bool grad, const double (*kvo)[NU], const double *pn1, const double *pn2)
+{
+    typedef Map<NH> M;
+    if (ff) {
+        stw(L, k, M::KV + 0, kvo[0][0]);  stw(L, k, M::KV + 1, kvo[0][1]);
+        stw(L, k, M::KV2 + 0, kvo[1][0]); stw(L, k, M::KV2 + 1, kvo[1][1]);
+    }
+    if (grad) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { stw(L, k, M::PV + i, pn1[i]); stw(L, k, M::PV2 + i, pn2[i]); }
+    }
+}
 
 template <int NH, int KIND>
 DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu,
@@ -1160,7 +1181,9 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, do
 {
     BsOut t;
     stage_Bs_rows<NH, KIND>(L, o, pc, k, sigma_mu, t);
-    stage_Bs_rec<NH, KIND, false>(L, k, t, pn1, pn2);
+    double kvo[2][NU];
+    stage_Bs_rec<KIND>(L, t, pn1, pn2, kvo);
+    store_rec<NH>(L, k, KIND != LAST, KIND != FIRST, kvo, pn1, pn2);
 }
 
 template <int NH>
@@ -1389,7 +1412,6 @@ DEV double uniform(double v)
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
-DEV double from_next_lane(double v) { return __shfl_down(v, 1, 64); }
 
 DEV AB bcast_ab(const AB &a, int k)
 {
@@ -1419,6 +1441,27 @@ DEV Lane stage_lane(const Lane &C, unsigned j, bool writer)
     return S;
 }
 
+// Values handed from lane to lane in the recursions: lane j takes the value of lane j+1
+// (or j-1); the lane at the end of the wavefront takes `edge`.
+DEV double from_lane_above(double v, double edge)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);      // wave_shl:1
+}
+DEV double from_lane_below(double v, double edge)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);      // wave_shr:1
+}
+
+// The recursions run as a pipeline over the lanes.  Every lane keeps the operands of its own
+// stage and, each step, recomputes its stage from what the neighbouring lane produced in the
+// step before.  The lane at the start of the chain has its true input from the first step
+// on, so after s steps the first s stages hold their true results, and a stage whose input
+// is true reproduces the same result in every later step.  After as many steps as there are
+// stages all of them are true; what the other lanes computed meanwhile is never used.
 template <int NH, bool ONE>
 __device__ __attribute__((noinline)) void coop_B0(Lane C, PC<NH> pc, const mpcx_opts *op, bool sp_have, int sp_mode,
                                                   double sp_sigma_mu, double sp_alpha, int m_total, ldouble *ret)
@@ -1429,27 +1472,26 @@ __device__ __attribute__((noinline)) void coop_B0(Lane C, PC<NH> pc, const mpcx_
     const int N = C.N;
     const int j = (int)threadIdx.x;
     coop_sync();
-    double Pn[15], pn[NX], cvx[NX], cqpi[NX];
+    // what the block of stages above hands down: P, p of its lowest stage, and that stage's
+    // updated state and multiplier
+    double cP[15], cp[NX], cvx[NX], cqpi[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { pn[i] = 0.0; cvx[i] = 0.0; cqpi[i] = 0.0; }
+    for (int i = 0; i < NX; ++i) { cp[i] = 0.0; cvx[i] = 0.0; cqpi[i] = 0.0; }
 #pragma unroll
-    for (int i = 0; i < 15; ++i) Pn[i] = 0.0;
+    for (int i = 0; i < 15; ++i) cP[i] = 0.0;
     double ng = 0.0, nb = 0.0, nd = 0.0, nm = 0.0, sum = 0.0;
     // blocks of 64 consecutive stages, the last block first (ONE: N < 64, a single block)
     for (int k0 = ONE ? 0 : (N / 64) * 64; k0 >= 0; k0 -= 64) {
         const int kj = k0 + j;
         const Lane S = stage_lane(C, (unsigned)kj, true);
-        // the stage above supplies its updated state and multiplier: the next lane, or the
-        // first stage of the block before (cvx, cqpi)
         double vx[NX], qpi[NX], vxn[NX], qpin[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) { vx[i] = 0.0; qpi[i] = 0.0; }
         if (kj <= N) stage_B0_peek<NH>(S, 0, sp, vx, qpi);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const double a = from_next_lane(vx[i]), b = from_next_lane(qpi[i]);
-            vxn[i] = (j == 63) ? cvx[i] : a;
-            qpin[i] = (j == 63) ? cqpi[i] : b;
+            vxn[i] = from_lane_above(vx[i], cvx[i]);
+            qpin[i] = from_lane_above(qpi[i], cqpi[i]);
             cvx[i] = bcast(vx[i], 0);
             cqpi[i] = bcast(qpi[i], 0);
         }
@@ -1457,24 +1499,41 @@ __device__ __attribute__((noinline)) void coop_B0(Lane C, PC<NH> pc, const mpcx_
         if (kj == 0) stage_B0_rows<NH, FIRST>(S, o, pc, 0, sp, vxn, qpin, t);
         else if (kj < N) stage_B0_rows<NH, MID>(S, o, pc, 0, sp, vxn, qpin, t);
         else if (kj == N) stage_B0_rows<NH, LAST>(S, o, pc, 0, sp, vxn, qpin, t);
-        // recursion and reductions over the stages of the block, downwards
+        // reductions over the stages of the block, downwards
         const int kend = (N - k0 < 63) ? N - k0 : 63;
         for (int kk = kend; kk >= 0; --kk) {
-            B0Out in;
-#pragma unroll
-            for (int i = 0; i < NZ; ++i) { in.gt[i] = bcast(t.gt[i], kk); in.Ht[i] = bcast(t.Ht[i], kk); }
-            in.hxx = bcast(t.hxx, kk); in.hxy = bcast(t.hxy, kk); in.hyy = bcast(t.hyy, kk);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) in.rb[i] = bcast(t.rb[i], kk);
-            in.ab = bcast_ab(t.ab, kk);
             ng = dmax(ng, bcast(t.ng, kk)); nb = dmax(nb, bcast(t.nb, kk));
             nd = dmax(nd, bcast(t.nd, kk)); nm = dmax(nm, bcast(t.nm, kk));
             sum = sum + bcast(t.ssum, kk);
-            const Lane R = stage_lane(C, (unsigned)(k0 + kk), j == 0);
-            // (stage 0 also stores its P, into a slot nobody reads)
-            if (k0 + kk == N) stage_B0_ric<NH, LAST, true>(R, 0, in, Pn, pn);
-            else stage_B0_ric<NH, MID, true>(R, 0, in, Pn, pn);
         }
+        // Riccati recursion down the lanes
+        double Po[15], po[NX];
+        RicOut ro = {};
+#pragma unroll
+        for (int i = 0; i < NX; ++i) po[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) Po[i] = 0.0;
+        if (kj == N) stage_B0_ric<LAST>(S, t, Po, po, ro);
+        const int steps = (N - k0 < 64) ? N - k0 : 64;       // stages below N in this block
+        for (int s = 0; s < steps; ++s) {
+            double Pi[15], pi[NX];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) Pi[i] = from_lane_above(Po[i], cP[i]);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) pi[i] = from_lane_above(po[i], cp[i]);
+            if (kj < N) {
+                stage_B0_ric<MID>(S, t, Pi, pi, ro);
+#pragma unroll
+                for (int i = 0; i < 15; ++i) Po[i] = Pi[i];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) po[i] = pi[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 15; ++i) cP[i] = bcast(Po[i], 0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) cp[i] = bcast(po[i], 0);
+        if (kj <= N) store_ric<NH>(S, 0, kj < N, kj > 0, ro, Po);
     }
     coop_sync();
     ret[0 * 64] = ng; ret[1 * 64] = nb; ret[2 * 64] = nd; ret[3 * 64] = nm;
@@ -1488,9 +1547,9 @@ __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_
     const int N = C.N;
     const int j = (int)threadIdx.x;
     coop_sync();
-    double pn1[NX], pn2[NX];
+    double c1[NX], c2[NX];          // p of the lowest stage of the block above, both systems
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { pn1[i] = 0.0; pn2[i] = 0.0; }
+    for (int i = 0; i < NX; ++i) { c1[i] = 0.0; c2[i] = 0.0; }
     for (int k0 = ONE ? 0 : (N / 64) * 64; k0 >= 0; k0 -= 64) {
         const int kj = k0 + j;
         const Lane S = stage_lane(C, (unsigned)kj, true);
@@ -1498,23 +1557,27 @@ __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_
         if (kj == 0) stage_Bs_rows<NH, FIRST>(S, o, pc, 0, sigma_mu, t);
         else if (kj < N) stage_Bs_rows<NH, MID>(S, o, pc, 0, sigma_mu, t);
         else if (kj == N) stage_Bs_rows<NH, LAST>(S, o, pc, 0, sigma_mu, t);
-        const int kend = (N - k0 < 63) ? N - k0 : 63;
-        for (int kk = kend; kk >= 0; --kk) {
-            BsOut in;
+        double o1[NX], o2[NX], kvo[2][NU] = {{0.0, 0.0}, {0.0, 0.0}};
 #pragma unroll
-            for (int i = 0; i < NZ; ++i) { in.gt1[i] = bcast(t.gt1[i], kk); in.gt2[i] = bcast(t.gt2[i], kk); }
+        for (int i = 0; i < NX; ++i) { o1[i] = 0.0; o2[i] = 0.0; }
+        if (kj == N) stage_Bs_rec<LAST>(S, t, o1, o2, kvo);
+        const int steps = (N - k0 < 64) ? N - k0 : 64;
+        for (int s = 0; s < steps; ++s) {
+            double i1[NX], i2[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                in.prb[i] = bcast(t.prb[i], kk); in.k0[i] = bcast(t.k0[i], kk); in.k1[i] = bcast(t.k1[i], kk);
+                i1[i] = from_lane_above(o1[i], c1[i]);
+                i2[i] = from_lane_above(o2[i], c2[i]);
             }
-            in.l10 = bcast(t.l10, kk); in.d0 = bcast(t.d0, kk); in.d1 = bcast(t.d1, kk);
-            in.ab = bcast_ab(t.ab, kk);
-            const int k = k0 + kk;
-            const Lane R = stage_lane(C, (unsigned)k, j == 0);
-            if (k == N) stage_Bs_rec<NH, LAST, true>(R, 0, in, pn1, pn2);
-            else if (k > 0) stage_Bs_rec<NH, MID, true>(R, 0, in, pn1, pn2);
-            else stage_Bs_rec<NH, FIRST, true>(R, 0, in, pn1, pn2);
+            if (kj < N) {
+                stage_Bs_rec<MID>(S, t, i1, i2, kvo);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { o1[i] = i1[i]; o2[i] = i2[i]; }
+            }
         }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { c1[i] = bcast(o1[i], 0); c2[i] = bcast(o2[i], 0); }
+        if (kj <= N) store_rec<NH>(S, 0, kj < N, kj > 0, kvo, o1, o2);
     }
     coop_sync();
 }
@@ -1527,16 +1590,16 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
     const int N = C.N;
     const int j = (int)threadIdx.x;
     coop_sync();
-    double dx[NS][NX];           // state step entering the stage the recursion stands at
+    double cdx[NS][NX];          // state step that enters the first stage of the block
 #pragma unroll
     for (int q = 0; q < NS; ++q)
 #pragma unroll
-        for (int i = 0; i < NX; ++i) dx[q][i] = 0.0;
+        for (int i = 0; i < NX; ++i) cdx[q][i] = 0.0;
     double alpha[2] = {1.0, 1.0}, s1 = 0.0, s2 = 0.0;
     for (int k0 = 0; ONE ? (k0 == 0) : (k0 <= N); k0 += 64) {
         const int kj = k0 + j;
         const Lane S = stage_lane(C, (unsigned)kj, true);
-        // what the recursion needs of every stage of the block
+        // what the recursion needs of this lane's stage
         AB ab = {};
         double rb[NX], kg[NU][NX], kv[NS][NU];
 #pragma unroll
@@ -1557,39 +1620,32 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
                 kv[q][1] = ldw(S, 0, M::KV + q * M::SOL2 + 1);
             }
         }
-        // the recursion; the lane of a stage keeps the state step that enters it
-        double mydx[NS][NX];
+        // the recursion up the lanes: dxi = state step entering this lane's stage, dxo = leaving it
+        const int kend = (N - k0 < 63) ? N - k0 : 63;
+        double dxi[NS][NX], dxo[NS][NX];
 #pragma unroll
         for (int q = 0; q < NS; ++q)
 #pragma unroll
-            for (int i = 0; i < NX; ++i) mydx[q][i] = 0.0;
-        const int kend = (N - k0 < 63) ? N - k0 : 63;
-        for (int kk = 0; kk <= kend; ++kk) {
+            for (int i = 0; i < NX; ++i) { dxi[q][i] = 0.0; dxo[q][i] = 0.0; }
+        for (int s = 0; s <= kend; ++s) {
 #pragma unroll
-            for (int q = 0; q < NS; ++q)
+            for (int q = 0; q < NS; ++q) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) mydx[q][i] = (j == kk) ? dx[q][i] : mydx[q][i];
-            if (k0 + kk < N) {
-                const AB abk = bcast_ab(ab, kk);
-                double rbk[NX], kgk[NU][NX];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    rbk[i] = bcast(rb[i], kk); kgk[0][i] = bcast(kg[0][i], kk); kgk[1][i] = bcast(kg[1][i], kk);
-                }
-#pragma unroll
-                for (int q = 0; q < NS; ++q) {
-                    const double kvk[NU] = {bcast(kv[q][0], kk), bcast(kv[q][1], kk)};
-                    double du[NU], dxn[NX];
-                    F_rec(C, abk, kgk, kvk, rbk, dx[q], du, dxn);
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) dx[q][i] = dxn[i];
+                for (int i = 0; i < NX; ++i) dxi[q][i] = from_lane_below(dxo[q][i], cdx[q][i]);
+                if (kj < N) {
+                    double du[NU];
+                    F_rec(C, ab, kg, kv[q], rb, dxi[q], du, dxo[q]);
                 }
             }
         }
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+            for (int i = 0; i < NX; ++i) cdx[q][i] = bcast(dxo[q][i], 63);
         FAcc a = {{1.0, 1.0}, 0.0, 0.0};
-        if (kj == 0) stage_F<NH, FIRST, NS>(S, o, pc, 0, sigma_mu, mydx, a);
-        else if (kj < N) stage_F<NH, MID, NS>(S, o, pc, 0, sigma_mu, mydx, a);
-        else if (kj == N) stage_F<NH, LAST, NS>(S, o, pc, 0, sigma_mu, mydx, a);
+        if (kj == 0) stage_F<NH, FIRST, NS>(S, o, pc, 0, sigma_mu, dxi, a);
+        else if (kj < N) stage_F<NH, MID, NS>(S, o, pc, 0, sigma_mu, dxi, a);
+        else if (kj == N) stage_F<NH, LAST, NS>(S, o, pc, 0, sigma_mu, dxi, a);
         for (int kk = 0; kk <= kend; ++kk) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
