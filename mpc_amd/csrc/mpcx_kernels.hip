@@ -496,9 +496,11 @@ DEV void row_rm(int mode, double sigma_mu, double jda, double ll, double lu, dou
 // ---------------------------------------------------------------------------
 struct LAcc { double rs, re, ri, rc, cost; };
 
-template <int NH, int KIND>
+// nxt (single-problem mode only): state, step and multiplier of stage k+1, read by the caller
+// before any lane has overwritten them; otherwise they are loaded here
+template <int NH, int KIND, bool COOP = false>
 DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, bool first,
-                 double *xk, double *pik, LAcc &a)
+                 double *xk, double *pik, LAcc &a, const double *nxt = nullptr)
 {
     typedef Map<NH> M;
     const double thr0 = o.thr0, mu0 = o.mu0;
@@ -513,9 +515,9 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
         for (int c = 0; c < NU; ++c) { uk[c] = ldw(L, k, M::U + c); vu[c] = ldw(L, k, M::V + c); }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            xn1[i] = ldw(L, k + 1, M::X + i);
-            vxn1[i] = ldw(L, k + 1, M::V + NU + i);
-            pin1[i] = ldw(L, k + 1, M::QPI + i);
+            xn1[i] = COOP ? nxt[i] : ldw(L, k + 1, M::X + i);
+            vxn1[i] = COOP ? nxt[NX + i] : ldw(L, k + 1, M::V + NU + i);
+            pin1[i] = COOP ? nxt[2 * NX + i] : ldw(L, k + 1, M::QPI + i);
         }
     }
 #pragma unroll
@@ -1424,7 +1426,8 @@ DEV AB bcast_ab(const AB &a, int k)
     return r;
 }
 
-// stores of one lane become visible to the loads of the others (same wavefront, same CU)
+// stores of one lane become visible to the loads of the others (same wavefront, same CU),
+// and loads issued so far have their data before any later store is issued
 DEV void coop_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1439,6 +1442,20 @@ DEV Lane stage_lane(const Lane &C, unsigned j, bool writer)
     S.lane = j * (unsigned)(C.F * 64) + C.lane;
     S.writer = writer;
     return S;
+}
+
+// the problem of lane p as wave-uniform values: C.lane = p is its column in the workspace
+template <int NH>
+DEV void problem_of_lane(const Lane &L, const PC<NH> &pc, ldouble *pc_lds, int p, Lane &C, PC<NH> &pcc)
+{
+    C = L;
+    C.lane = (unsigned)p;
+    C.b = (unsigned)__builtin_amdgcn_readlane((int)L.b, p);
+    C.nobs = __builtin_amdgcn_readlane(L.nobs, p);
+    C.h = bcast(L.h, p); C.hh = bcast(L.hh, p); C.h6 = bcast(L.h6, p);
+    C.hB = bcast(L.hB, p); C.invL = bcast(L.invL, p);
+    pcc.p = pc_lds + p;
+    pcc.lmk = bcast(pc.lmk, p);
 }
 
 // Values handed from lane to lane in the recursions: lane j takes the value of lane j+1
@@ -1661,6 +1678,58 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
     return alpha[0];
 }
 
+// sweep L has no recursion: every stage is linearised at its own (new) state, which its lane
+// forms from the stage's own iterate and step exactly as the stage before would have
+template <int NH, bool ONE>
+__device__ __attribute__((noinline)) void coop_L(Lane C, PC<NH> pc, const mpcx_opts *op, bool first, ldouble *ret)
+{
+    typedef Map<NH> M;
+    const mpcx_opts &o = *op;
+    const int N = C.N;
+    const int j = (int)threadIdx.x;
+    coop_sync();
+    LAcc tot = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; ONE ? (k0 == 0) : (k0 <= N); k0 += 64) {
+        const int kj = k0 + j;
+        const Lane S = stage_lane(C, (unsigned)kj, true);
+        // everything a lane reads of its own and of the next stage, before any lane stores
+        double xk[NX], pik[NX], nxt[3 * NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xk[i] = 0.0; pik[i] = 0.0; nxt[i] = nxt[NX + i] = nxt[2 * NX + i] = 0.0; }
+        if (kj <= N) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const double x0 = ldw(S, 0, M::X + i), v0 = ldw(S, 0, M::V + NU + i), q0 = ldw(S, 0, M::QPI + i);
+                xk[i] = first ? x0 : x0 + v0;
+                pik[i] = (kj > 0) ? q0 : 0.0;
+            }
+        }
+        if (kj < N) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                nxt[i] = ldw(S, 1, M::X + i);
+                nxt[NX + i] = ldw(S, 1, M::V + NU + i);
+                nxt[2 * NX + i] = ldw(S, 1, M::QPI + i);
+            }
+        }
+        coop_sync();
+        // (the three kinds may run in any order: each lane reads and writes its own stage only)
+        LAcc a = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if (kj == 0) stage_L<NH, FIRST, true>(S, o, pc, 0, first, xk, pik, a, nxt);
+        else if (kj < N) stage_L<NH, MID, true>(S, o, pc, 0, first, xk, pik, a, nxt);
+        else if (kj == N) stage_L<NH, LAST, true>(S, o, pc, 0, first, xk, pik, a, nxt);
+        const int kend = (N - k0 < 63) ? N - k0 : 63;
+        for (int kk = 0; kk <= kend; ++kk) {
+            tot.rs = dmax(tot.rs, bcast(a.rs, kk)); tot.re = dmax(tot.re, bcast(a.re, kk));
+            tot.ri = dmax(tot.ri, bcast(a.ri, kk)); tot.rc = dmax(tot.rc, bcast(a.rc, kk));
+            tot.cost = tot.cost + bcast(a.cost, kk);
+        }
+    }
+    coop_sync();
+    ret[0 * 64] = tot.rs; ret[1 * 64] = tot.re; ret[2 * 64] = tot.ri; ret[3 * 64] = tot.rc;
+    ret[4 * 64] = tot.cost;
+}
+
 // ---------------------------------------------------------------------------
 // the fused solve.  Every lane runs a small state machine over its own problem;
 // the wavefront executes the sweeps in a fixed order each TICK and a lane joins
@@ -1821,6 +1890,23 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             }
             STAMP(0, st_a);
             const bool st_b = (state == LS_LIN);
+            // few problems in the wavefront: sweep L of each with a lane per stage
+            const unsigned long long lin_mask = __ballot(state == LS_LIN);
+            const bool coop_lin = !o.rti && (__popcll(lin_mask) + n_qp <= MPCX_COOP_MAX);
+            if (coop_lin) {
+                for (unsigned long long rest = lin_mask; rest != 0; rest &= rest - 1) {
+                    const int p = __ffsll((long long)rest) - 1;
+                    Lane C;
+                    PC<NH> pcc;
+                    problem_of_lane<NH>(L, pc, (ldouble *)pc_lds, p, C, pcc);
+                    const bool fp = __builtin_amdgcn_readlane((int)first, p) != 0;
+                    if (N < 64) coop_L<NH, true>(C, pcc, op, fp, ret);
+                    else coop_L<NH, false>(C, pcc, op, fp, ret);
+                    const double r0 = uniform(ret[0 * 64]), r1 = uniform(ret[1 * 64]), r2 = uniform(ret[2 * 64]),
+                                 r3 = uniform(ret[3 * 64]), r4 = uniform(ret[4 * 64]);
+                    if ((int)threadIdx.x == p) { res[0] = r0; res[1] = r1; res[2] = r2; res[3] = r3; cost = r4; }
+                }
+            }
             if (state == LS_LIN) {
                 if (o.rti && !first) {
                     // real-time iteration: apply the one step, report the new objective
@@ -1829,10 +1915,12 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                     status = MPCX_SUCCESS;
                     state = LS_OUT;
                 } else {
-                    sweep_L<NH>(L, pc, op, first, ret);
+                    if (!coop_lin) {
+                        sweep_L<NH>(L, pc, op, first, ret);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) res[i] = ret[i * 64];
-                    cost = ret[4 * 64];
+                        for (int i = 0; i < 4; ++i) res[i] = ret[i * 64];
+                        cost = ret[4 * 64];
+                    }
                     first = false;
                     state = LS_OUT;
                     if (!(finite_d(res[0]) && finite_d(res[1]) && finite_d(res[2]) && finite_d(res[3]))) {
@@ -1858,15 +1946,9 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         if (__popcll(qp_mask) <= MPCX_COOP_MAX) {
             for (unsigned long long rest = qp_mask; rest != 0; rest &= rest - 1) {
                 const int p = __ffsll((long long)rest) - 1;
-                Lane C = L;
-                C.lane = (unsigned)p;
-                C.b = (unsigned)__builtin_amdgcn_readlane((int)L.b, p);
-                C.nobs = __builtin_amdgcn_readlane(L.nobs, p);
-                C.h = bcast(L.h, p); C.hh = bcast(L.hh, p); C.h6 = bcast(L.h6, p);
-                C.hB = bcast(L.hB, p); C.invL = bcast(L.invL, p);
+                Lane C;
                 PC<NH> pcc;
-                pcc.p = (ldouble *)pc_lds + p;
-                pcc.lmk = bcast(pc.lmk, p);
+                problem_of_lane<NH>(L, pc, (ldouble *)pc_lds, p, C, pcc);
                 Step s;
                 s.have = __builtin_amdgcn_readlane((int)sp.have, p) != 0;
                 s.mode = __builtin_amdgcn_readlane(sp.mode, p);
