@@ -345,15 +345,32 @@ DEV void mul_AB(const Lane &L, const AB &ab, const double *dx, const double *du,
 // known at compile time and a stage is ONE basic block: all its loads can be
 // issued before the first one is needed.
 // ---------------------------------------------------------------------------
-enum { FIRST = 0, MID = 1, LAST = 2 };
+// ANY: the kind is a run-time property of the lane (single-problem mode, where the lanes of a
+// wavefront work on different stages).  The code of a stage is then the code of a middle
+// stage, every row and variable computed, and what the stage does not have is kept out of the
+// results by selects; for the three fixed kinds the same selects fold away at compile time.
+enum { FIRST = 0, MID = 1, LAST = 2, ANY = 3 };
+struct KR { bool first, last; };
 
-template <int KIND> DEV constexpr bool row_present(int r)
+template <int KIND> DEV constexpr bool row_present(int r)      // can a stage of this kind have row r
 {
-    return (r < NU) ? (KIND != LAST) : (r < 9) ? (KIND != FIRST) : (KIND == MID);
+    return (KIND == ANY) ? true : (r < NU) ? (KIND != LAST) : (r < 9) ? (KIND != FIRST) : (KIND == MID);
 }
-template <int KIND> DEV constexpr bool var_present(int j)   // is v[j] a variable of this stage
+template <int KIND> DEV constexpr bool var_present(int j)      // ... have v[j] as a variable
 {
-    return (j < NU) ? (KIND != LAST) : (KIND != FIRST);
+    return (KIND == ANY) ? true : (j < NU) ? (KIND != LAST) : (KIND != FIRST);
+}
+template <int KIND> DEV bool is_first(const KR &kr) { return (KIND == ANY) ? kr.first : (KIND == FIRST); }
+template <int KIND> DEV bool is_last(const KR &kr) { return (KIND == ANY) ? kr.last : (KIND == LAST); }
+template <int KIND> DEV bool row_on(const KR &kr, int r)       // does this lane's stage have row r
+{
+    if (KIND != ANY) return row_present<KIND>(r);
+    return (r < NU) ? !kr.last : (r < 9) ? !kr.first : !(kr.first || kr.last);
+}
+template <int KIND> DEV bool var_on(const KR &kr, int j)
+{
+    if (KIND != ANY) return var_present<KIND>(j);
+    return (j < NU) ? !kr.last : !kr.first;
 }
 
 // Per-lane problem constants live in LDS as [field][lane] (one ds_read_b64 per
@@ -392,11 +409,17 @@ DEV void fill_pc(const Lane &L, const mpcx_opts &o, PC<NH> &pc)
 
 // bounds of row r (terminal state box for KIND == LAST)
 template <int NH, int KIND>
-DEV void row_bounds(const Lane &L, const PC<NH> &pc, int r, double &lo, double &up)
+DEV void row_bounds(const Lane &L, const PC<NH> &pc, const KR &kr, int r, double &lo, double &up)
 {
     if (r < NU) { lo = pc.get(C_LBU + r); up = pc.get(C_UBU + r); }
     else if (r < ROW_G0) {
         if (KIND == LAST) { lo = pc.get(C_LBXE + r - NU); up = pc.get(C_UBXE + r - NU); }
+        else if (KIND == ANY) {
+            const double le = pc.get(C_LBXE + r - NU), ue = pc.get(C_UBXE + r - NU);
+            const double ls = pc.get(C_LBX + r - NU), us = pc.get(C_UBX + r - NU);
+            lo = kr.last ? le : ls;
+            up = kr.last ? ue : us;
+        }
         else { lo = pc.get(C_LBX + r - NU); up = pc.get(C_UBX + r - NU); }
     }
     else if (r < 9) { lo = pc.get(C_LG + r - ROW_G0); up = pc.get(C_UG + r - ROW_G0); }
@@ -434,7 +457,7 @@ DEV double jdot(int r, double jx, double jy, const double *v)
 
 // cost gradient g and Gauss-Newton + LM diagonal Hd of a stage at (x, u)
 template <int NH, int KIND>
-DEV void cost_terms(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, const double *x,
+DEV void cost_terms(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, const KR &kr, const double *x,
                     const double *u, double *g, double *Hd)
 {
     if (KIND != LAST) {
@@ -445,7 +468,8 @@ DEV void cost_terms(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, const d
             Hd[j] = hw + pc.lmk;
             g[j] = hw * z;
         }
-    } else {
+    }
+    if (KIND == LAST) {
         Hd[0] = Hd[1] = 0.0;
         g[0] = g[1] = 0.0;
 #pragma unroll
@@ -455,18 +479,33 @@ DEV void cost_terms(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, const d
             g[NU + i] = we * (x[i] - pc.get(C_GOAL + i));
         }
     }
+    if (KIND == ANY) {
+        const bool e = kr.last;
+        Hd[0] = e ? 0.0 : Hd[0];
+        Hd[1] = e ? 0.0 : Hd[1];
+        g[0] = e ? 0.0 : g[0];
+        g[1] = e ? 0.0 : g[1];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double we = pc.get(C_WE + i);
+            const double he = we + o.lm, ge = we * (x[i] - pc.get(C_GOAL + i));
+            Hd[NU + i] = e ? he : Hd[NU + i];
+            g[NU + i] = e ? ge : g[NU + i];
+        }
+    }
 }
 
 template <int NH, int KIND>
-DEV void load_xu(const Lane &L, int k, double *x, double *u)
+DEV void load_xu(const Lane &L, int k, const KR &kr, double *x, double *u)
 {
     typedef Map<NH> M;
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = ldw(L, k, M::X + i);
     u[0] = u[1] = 0.0;
     if (KIND != LAST) {
-        u[0] = ldw(L, k, M::U + 0);
-        u[1] = ldw(L, k, M::U + 1);
+        const double u0 = ldw(L, k, M::U + 0), u1 = ldw(L, k, M::U + 1);
+        u[0] = is_last<KIND>(kr) ? 0.0 : u0;
+        u[1] = is_last<KIND>(kr) ? 0.0 : u1;
     }
 }
 
@@ -500,7 +539,7 @@ struct LAcc { double rs, re, ri, rc, cost; };
 // before any lane has overwritten them; otherwise they are loaded here
 template <int NH, int KIND, bool COOP = false>
 DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, bool first,
-                 double *xk, double *pik, LAcc &a, const double *nxt = nullptr)
+                 double *xk, double *pik, LAcc &a, const KR &kr = KR{false, false}, const double *nxt = nullptr)
 {
     typedef Map<NH> M;
     const double thr0 = o.thr0, mu0 = o.mu0;
@@ -534,6 +573,7 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
 #pragma unroll
         for (int c = 0; c < NU; ++c) {
             uk[c] = first ? uk[c] : uk[c] + vu[c];
+            uk[c] = is_last<KIND>(kr) ? 0.0 : uk[c];
             stw(L, k, M::U + c, uk[c]);
         }
 #pragma unroll
@@ -545,42 +585,49 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
         for (int i = 0; i < NX; ++i) {
             double bv = xn[i] - xn1[i];
             stw(L, k, M::BV + i, bv);
-            a.re = dmax(a.re, dabs(bv));
+            a.re = is_last<KIND>(kr) ? a.re : dmax(a.re, dabs(bv));
         }
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) stw(L, k, M::X + i, xk[i]);
     // stationarity of the Lagrangian
     double g[NZ], Hd[NZ], gl[NZ];
-    cost_terms<NH, KIND>(L, o, pc, xk, uk, g, Hd);
+    cost_terms<NH, KIND>(L, o, pc, kr, xk, uk, g, Hd);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) gl[j] = g[j];
-    if (KIND != LAST) add_BAt(L, ab, pin1, gl);
+    if (KIND != LAST) {
+        double gn[NZ];
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) gn[j] = gl[j];
+        add_BAt(L, ab, pin1, gn);
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) gl[j] = is_last<KIND>(kr) ? gl[j] : gn[j];
+    }
     if (KIND != FIRST) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) gl[NU + i] = gl[NU + i] - pik[i];
+        for (int i = 0; i < NX; ++i) gl[NU + i] = is_first<KIND>(kr) ? gl[NU + i] : gl[NU + i] - pik[i];
     }
     double vq[NZ];
 #pragma unroll
     for (int j = 0; j < NZ; ++j) vq[j] = 0.0;
-    if (KIND == FIRST) {
+    if (KIND == FIRST || KIND == ANY) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             double d0 = pc.get(C_X0 + i) - xk[i];
-            vq[NU + i] = d0;
-            a.ri = dmax(a.ri, dabs(d0));
+            vq[NU + i] = is_first<KIND>(kr) ? d0 : 0.0;
+            a.ri = is_first<KIND>(kr) ? dmax(a.ri, dabs(d0)) : a.ri;
         }
     }
     // rows: the multipliers of the last QP enter the residuals, then the cold start replaces them
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
         if (!row_present<KIND>(r)) continue;
-        const bool pr = (r < 9) || (r - 9 < L.nobs);
+        const bool pr = row_on<KIND>(kr, r) && ((r < 9) || (r - 9 < L.nobs));
         double c, jx, jy, lo, up;
         row_geom<NH>(pc, r, xk, uk, c, jx, jy);
-        row_bounds<NH, KIND>(L, pc, r, lo, up);
+        row_bounds<NH, KIND>(L, pc, kr, r, lo, up);
         double dl = lu[r] - ll[r];
-        if (r < ROW_G0) gl[r] = gl[r] + dl;
+        if (r < ROW_G0) gl[r] = pr ? gl[r] + dl : gl[r];
         else {
             gl[2] = pr ? fma(jx, dl, gl[2]) : gl[2];
             gl[3] = pr ? fma(jy, dl, gl[3]) : gl[3];
@@ -596,7 +643,8 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
             tl = vq[r] - dlo;
             tu = dup - vq[r];
             const bool bl = tl < thr0, bu = tu < thr0;
-            vq[r] = bl ? (bu ? 0.5 * (dlo + dup) : dlo + thr0) : (bu ? dup - thr0 : vq[r]);
+            const double vn = bl ? (bu ? 0.5 * (dlo + dup) : dlo + thr0) : (bu ? dup - thr0 : vq[r]);
+            vq[r] = pr ? vn : vq[r];
             tu = bu ? thr0 : tu;
             tl = bl ? thr0 : tl;
         } else {
@@ -615,13 +663,13 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
     }
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
-        if (var_present<KIND>(j)) a.rs = dmax(a.rs, dabs(gl[j]));
+        if (var_present<KIND>(j)) a.rs = var_on<KIND>(kr, j) ? dmax(a.rs, dabs(gl[j])) : a.rs;
         stw(L, k, M::V + j, vq[j]);
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) stw(L, k, M::QPI + i, 0.0);
     // objective: summed per stage, then over the stages
-    double ck = 0.0;
+    double ck = 0.0, cke = 0.0;
     if (KIND != LAST) {
 #pragma unroll
         for (int j = 0; j < NZ; ++j) {
@@ -629,14 +677,15 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
             double hw = (0.5 * L.h) * pc.get(C_W + j);
             ck = fma(hw * z, z, ck);
         }
-    } else {
+    }
+    if (KIND == LAST || KIND == ANY) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             double z = xk[i] - pc.get(C_GOAL + i);
-            ck = fma((0.5 * pc.get(C_WE + i)) * z, z, ck);
+            cke = fma((0.5 * pc.get(C_WE + i)) * z, z, cke);
         }
     }
-    a.cost = a.cost + ck;
+    a.cost = a.cost + (is_last<KIND>(kr) ? cke : ck);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         xk[i] = xn1[i];
@@ -696,7 +745,7 @@ struct B0Out {
 // multiplier of stage k+1.
 template <int NH, int KIND>
 DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, const Step &sp,
-                       const double *vxn, const double *qpin, B0Out &out)
+                       const double *vxn, const double *qpin, B0Out &out, const KR &kr = KR{false, false})
 {
     out.ng = out.nb = out.nd = out.nm = 0.0;
     typedef Map<NH> M;
@@ -705,7 +754,7 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
     double ssum = 0.0;
     double x[NX], u[NU], v[NZ], vo[NZ], dv[NZ], dva[NZ], qpi[NX], dpi[NX];
     double ll[M::R], lu[M::R], tl[M::R], tu[M::R], til_[M::R], tiu_[M::R];
-    load_xu<NH, KIND>(L, k, x, u);
+    load_xu<NH, KIND>(L, k, kr, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
         vo[j] = ldw(L, k, M::V + j);
@@ -741,7 +790,7 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
     for (int j = 0; j < NZ; ++j) {
         v[j] = vo[j];
         if (var_present<KIND>(j)) {
-            v[j] = sp.have ? fma(sp.alpha, dv[j], vo[j]) : vo[j];
+            v[j] = (sp.have && var_on<KIND>(kr, j)) ? fma(sp.alpha, dv[j], vo[j]) : vo[j];
             stw(L, k, M::V + j, v[j]);
         }
     }
@@ -749,17 +798,25 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             qpi[i] = sp.have ? fma(sp.alpha, dpi[i], qpi[i]) : qpi[i];
+            qpi[i] = is_first<KIND>(kr) ? 0.0 : qpi[i];
             stw(L, k, M::QPI + i, qpi[i]);
         }
     }
     double g[NZ], Ht[NZ], rg[NZ], hxx = 0.0, hxy = 0.0, hyy = 0.0;
-    cost_terms<NH, KIND>(L, o, pc, x, u, g, Ht);
+    cost_terms<NH, KIND>(L, o, pc, kr, x, u, g, Ht);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) rg[j] = fma(Ht[j], v[j], g[j]);
-    if (KIND != LAST) add_BAt(L, ab, qpin, rg);
+    if (KIND != LAST) {
+        double rn[NZ];
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) rn[j] = rg[j];
+        add_BAt(L, ab, qpin, rn);
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) rg[j] = is_last<KIND>(kr) ? rg[j] : rn[j];
+    }
     if (KIND != FIRST) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) rg[NU + i] = rg[NU + i] - qpi[i];
+        for (int i = 0; i < NX; ++i) rg[NU + i] = is_first<KIND>(kr) ? rg[NU + i] : rg[NU + i] - qpi[i];
     }
     // ---- rows ----
     double qrow[M::R], gjx[M::R], gjy[M::R];
@@ -767,10 +824,10 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
     for (int r = 0; r < M::R; ++r) {
         qrow[r] = 0.0; gjx[r] = 0.0; gjy[r] = 0.0;
         if (!row_present<KIND>(r)) continue;
-        const bool pr = (r < 9) || (r - 9 < L.nobs);
+        const bool pr = row_on<KIND>(kr, r) && ((r < 9) || (r - 9 < L.nobs));
         double c, jx, jy, lo, up;
         row_geom<NH>(pc, r, x, u, c, jx, jy);
-        row_bounds<NH, KIND>(L, pc, r, lo, up);
+        row_bounds<NH, KIND>(L, pc, kr, r, lo, up);
         const double dlo = lo - c, dup = up - c;
         double l_l = ll[r], l_u = lu[r], t_l = tl[r], t_u = tu[r];
         {
@@ -799,7 +856,7 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
         }
         double jv = jdot(r, jx, jy, v);
         double dlm = l_u - l_l;
-        if (r < ROW_G0) rg[r] = rg[r] + dlm;
+        if (r < ROW_G0) rg[r] = pr ? rg[r] + dlm : rg[r];
         else {
             rg[2] = pr ? fma(jx, dlm, rg[2]) : rg[2];
             rg[3] = pr ? fma(jy, dlm, rg[3]) : rg[3];
@@ -823,7 +880,7 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
         gjx[r] = jx;
         gjy[r] = jy;
         double w = l_l * til + l_u * tiu;
-        if (r < ROW_G0) Ht[r] = Ht[r] + w;
+        if (r < ROW_G0) Ht[r] = pr ? Ht[r] + w : Ht[r];
         else {
             double wx = w * jx, wy = w * jy;
             hxx = pr ? fma(wx, jx, hxx) : hxx;
@@ -836,14 +893,14 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
         stw(L, k, M::RG + j, rg[j]);
-        if (var_present<KIND>(j)) out.ng = dmax(out.ng, dabs(rg[j]));
+        if (var_present<KIND>(j)) out.ng = var_on<KIND>(kr, j) ? dmax(out.ng, dabs(rg[j])) : out.ng;
         gt[j] = rg[j];
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
         if (!row_present<KIND>(r)) continue;
-        const bool pr = (r < 9) || (r - 9 < L.nobs);
-        if (r < ROW_G0) gt[r] = gt[r] + qrow[r];
+        const bool pr = row_on<KIND>(kr, r) && ((r < 9) || (r - 9 < L.nobs));
+        if (r < ROW_G0) gt[r] = pr ? gt[r] + qrow[r] : gt[r];
         else {
             gt[2] = pr ? fma(gjx[r], qrow[r], gt[2]) : gt[2];
             gt[3] = pr ? fma(gjy[r], qrow[r], gt[3]) : gt[3];
@@ -862,7 +919,7 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
         for (int i = 0; i < NX; ++i) {
             out.rb[i] = out.rb[i] - vxn[i];
             stw(L, k, M::RB + i, out.rb[i]);
-            out.nb = dmax(out.nb, dabs(out.rb[i]));
+            out.nb = is_last<KIND>(kr) ? out.nb : dmax(out.nb, dabs(out.rb[i]));
         }
     }
 }
@@ -1057,13 +1114,14 @@ struct BsOut {
 
 // Bs, row part of stage k: the two right-hand sides, and the stored factors of the stage
 template <int NH, int KIND>
-DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu, BsOut &out)
+DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu, BsOut &out,
+                       const KR &kr = KR{false, false})
 {
     typedef Map<NH> M;
     double x[NX], u[NU], v[NZ], dva[NZ];
     double *gt1 = out.gt1, *gt2 = out.gt2;
     double ll[M::R], lu[M::R], tl[M::R], tu[M::R], til_[M::R], tiu_[M::R];
-    load_xu<NH, KIND>(L, k, x, u);
+    load_xu<NH, KIND>(L, k, kr, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
         v[j] = ldw(L, k, M::V + j);
@@ -1103,10 +1161,10 @@ DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
         if (!row_present<KIND>(r)) continue;
-        const bool pr = (r < 9) || (r - 9 < L.nobs);
+        const bool pr = row_on<KIND>(kr, r) && ((r < 9) || (r - 9 < L.nobs));
         double c, jx, jy, lo, up;
         row_geom<NH>(pc, r, x, u, c, jx, jy);
-        row_bounds<NH, KIND>(L, pc, r, lo, up);
+        row_bounds<NH, KIND>(L, pc, kr, r, lo, up);
         const double dlo = lo - c, dup = up - c;
         double jv = jdot(r, jx, jy, v);
         double rdl = (dlo - jv) + tl[r];
@@ -1122,7 +1180,7 @@ DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
         const double rml2 = ml - sigma_mu, rmu2 = mu_ - sigma_mu;
         const double q1 = fma(-ll[r], rdl, rml1) * til - fma(-lu[r], rdu, rmu1) * tiu;
         const double q2 = fma(-ll[r], rdl, rml2) * til - fma(-lu[r], rdu, rmu2) * tiu;
-        if (r < ROW_G0) { gt1[r] = gt1[r] + q1; gt2[r] = gt2[r] + q2; }
+        if (r < ROW_G0) { gt1[r] = pr ? gt1[r] + q1 : gt1[r]; gt2[r] = pr ? gt2[r] + q2 : gt2[r]; }
         else {
             gt1[2] = pr ? fma(jx, q1, gt1[2]) : gt1[2];
             gt1[3] = pr ? fma(jy, q1, gt1[3]) : gt1[3];
@@ -1235,12 +1293,12 @@ DEV void F_rec(const Lane &L, const AB &ab, const double (*kg)[NX], const double
 
 template <int NH, int KIND, int NS>
 DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu,
-                 double (*dx)[NX], FAcc &a)
+                 double (*dx)[NX], FAcc &a, const KR &kr = KR{false, false})
 {
     typedef Map<NH> M;
     double x[NX], u[NU], v[NZ], dva[NZ], dvk[NS][NZ], dxn[NS][NX];
     double ll[M::R], lu[M::R], tl[M::R], tu[M::R], til_[M::R], tiu_[M::R];
-    load_xu<NH, KIND>(L, k, x, u);
+    load_xu<NH, KIND>(L, k, kr, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
         v[j] = ldw(L, k, M::V + j);
@@ -1299,6 +1357,8 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, dou
         }
         if (KIND != LAST) {
             F_rec(L, ab, kg, kv[q], rb, dx[q], dvk[q], dxn[q]);
+            dvk[q][0] = is_last<KIND>(kr) ? 0.0 : dvk[q][0];
+            dvk[q][1] = is_last<KIND>(kr) ? 0.0 : dvk[q][1];
         }
 #pragma unroll
         for (int j = 0; j < NZ; ++j) stw(L, k, (NS == 1 ? M::DVA : M::DV + q * M::SOL2) + j, dvk[q][j]);
@@ -1309,10 +1369,10 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, dou
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
         if (!row_present<KIND>(r)) continue;
-        const bool pr = (r < 9) || (r - 9 < L.nobs);
+        const bool pr = row_on<KIND>(kr, r) && ((r < 9) || (r - 9 < L.nobs));
         double c, jx, jy, lo, up;
         row_geom<NH>(pc, r, x, u, c, jx, jy);
-        row_bounds<NH, KIND>(L, pc, r, lo, up);
+        row_bounds<NH, KIND>(L, pc, kr, r, lo, up);
         const double dlo = lo - c, dup = up - c;
         double jv = jdot(r, jx, jy, v);
         double rdl = (dlo - jv) + tl[r];
@@ -1513,9 +1573,8 @@ __device__ __attribute__((noinline)) void coop_B0(Lane C, PC<NH> pc, const mpcx_
             cqpi[i] = bcast(qpi[i], 0);
         }
         B0Out t = {};
-        if (kj == 0) stage_B0_rows<NH, FIRST>(S, o, pc, 0, sp, vxn, qpin, t);
-        else if (kj < N) stage_B0_rows<NH, MID>(S, o, pc, 0, sp, vxn, qpin, t);
-        else if (kj == N) stage_B0_rows<NH, LAST>(S, o, pc, 0, sp, vxn, qpin, t);
+        const KR kr = {kj == 0, kj == N};
+        if (kj <= N) stage_B0_rows<NH, ANY>(S, o, pc, 0, sp, vxn, qpin, t, kr);
         // reductions over the stages of the block, downwards
         const int kend = (N - k0 < 63) ? N - k0 : 63;
         for (int kk = kend; kk >= 0; --kk) {
@@ -1571,9 +1630,8 @@ __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_
         const int kj = k0 + j;
         const Lane S = stage_lane(C, (unsigned)kj, true);
         BsOut t = {};
-        if (kj == 0) stage_Bs_rows<NH, FIRST>(S, o, pc, 0, sigma_mu, t);
-        else if (kj < N) stage_Bs_rows<NH, MID>(S, o, pc, 0, sigma_mu, t);
-        else if (kj == N) stage_Bs_rows<NH, LAST>(S, o, pc, 0, sigma_mu, t);
+        const KR kr = {kj == 0, kj == N};
+        if (kj <= N) stage_Bs_rows<NH, ANY>(S, o, pc, 0, sigma_mu, t, kr);
         double o1[NX], o2[NX], kvo[2][NU] = {{0.0, 0.0}, {0.0, 0.0}};
 #pragma unroll
         for (int i = 0; i < NX; ++i) { o1[i] = 0.0; o2[i] = 0.0; }
@@ -1660,9 +1718,8 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
 #pragma unroll
             for (int i = 0; i < NX; ++i) cdx[q][i] = bcast(dxo[q][i], 63);
         FAcc a = {{1.0, 1.0}, 0.0, 0.0};
-        if (kj == 0) stage_F<NH, FIRST, NS>(S, o, pc, 0, sigma_mu, dxi, a);
-        else if (kj < N) stage_F<NH, MID, NS>(S, o, pc, 0, sigma_mu, dxi, a);
-        else if (kj == N) stage_F<NH, LAST, NS>(S, o, pc, 0, sigma_mu, dxi, a);
+        const KR kr = {kj == 0, kj == N};
+        if (kj <= N) stage_F<NH, ANY, NS>(S, o, pc, 0, sigma_mu, dxi, a, kr);
         for (int kk = 0; kk <= kend; ++kk) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
@@ -1713,11 +1770,9 @@ __device__ __attribute__((noinline)) void coop_L(Lane C, PC<NH> pc, const mpcx_o
             }
         }
         coop_sync();
-        // (the three kinds may run in any order: each lane reads and writes its own stage only)
         LAcc a = {0.0, 0.0, 0.0, 0.0, 0.0};
-        if (kj == 0) stage_L<NH, FIRST, true>(S, o, pc, 0, first, xk, pik, a, nxt);
-        else if (kj < N) stage_L<NH, MID, true>(S, o, pc, 0, first, xk, pik, a, nxt);
-        else if (kj == N) stage_L<NH, LAST, true>(S, o, pc, 0, first, xk, pik, a, nxt);
+        const KR kr = {kj == 0, kj == N};
+        if (kj <= N) stage_L<NH, ANY, true>(S, o, pc, 0, first, xk, pik, a, kr, nxt);
         const int kend = (N - k0 < 63) ? N - k0 : 63;
         for (int kk = 0; kk <= kend; ++kk) {
             tot.rs = dmax(tot.rs, bcast(a.rs, kk)); tot.re = dmax(tot.re, bcast(a.re, kk));
