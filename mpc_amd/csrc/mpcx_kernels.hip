@@ -104,8 +104,8 @@ struct Lane {
                           // of lane l is wave[(k*F + f) * 64 + l]
     const gdouble *pdata; // problem table (same in all lanes); field f of problem b at [f*B + b]
     size_t B;
-    bool writer;          // single-problem mode: this lane performs the stores of uniform data
-    unsigned lane;        // 0..63
+    unsigned lane;        // column of the workspace this lane works in, as a BYTE offset (8 * 0..63);
+                          // in single-problem mode it also carries the offset of the lane's stage
     unsigned b;           // problem this lane is solving
     int N;
     int nobs;
@@ -115,11 +115,19 @@ struct Lane {
 
 // The wave-uniform part of every address stays in scalar registers; only the
 // lane (or problem) index is a vector offset.
-DEV double ldw(const Lane &L, int k, int f) { return (L.wave + ((size_t)k * L.F + f) * 64)[L.lane]; }
-DEV void stw(const Lane &L, int k, int f, double v) { (L.wave + ((size_t)k * L.F + f) * 64)[L.lane] = v; }
+// (a 32-bit byte offset on a uniform base is the addressing mode global_load has: base in
+// scalar registers, offset in one vector register)
+typedef __attribute__((address_space(1))) char gchar;
+DEV gdouble *wsp(const Lane &L, int k, int f, unsigned extra)
+{
+    gchar *base = (gchar *)(L.wave + ((size_t)k * L.F + f) * 64);
+    return (gdouble *)(base + (L.lane + extra));
+}
+DEV double ldw(const Lane &L, int k, int f) { return *wsp(L, k, f, 0u); }
+DEV void stw(const Lane &L, int k, int f, double v) { *wsp(L, k, f, 0u) = v; }
 DEV double ldp(const Lane &L, int f) { return (L.pdata + (size_t)f * L.B)[L.b]; }
 // field f + df where df differs from lane to lane
-DEV double ldw_lane(const Lane &L, int k, int f, int df) { return (L.wave + ((size_t)k * L.F + f) * 64)[L.lane + 64u * (unsigned)df]; }
+DEV double ldw_lane(const Lane &L, int k, int f, int df) { return *wsp(L, k, f, 512u * (unsigned)df); }
 
 DEV double dabs(double a) { return (a < 0.0) ? -a : a; }
 DEV double dmax(double a, double b) { return (b > a) ? b : a; }
@@ -1496,11 +1504,10 @@ DEV void coop_sync()
 
 // C: the problem's Lane with C.lane = its column in the workspace; stage j of it is
 // addressed as stage 0 of a Lane whose "lane" is moved by j stages
-DEV Lane stage_lane(const Lane &C, unsigned j, bool writer)
+DEV Lane stage_lane(const Lane &C, unsigned j)
 {
     Lane S = C;
-    S.lane = j * (unsigned)(C.F * 64) + C.lane;
-    S.writer = writer;
+    S.lane = j * (unsigned)(C.F * 512) + C.lane;      // a wavefront's workspace is far below 4 GiB
     return S;
 }
 
@@ -1509,7 +1516,7 @@ template <int NH>
 DEV void problem_of_lane(const Lane &L, const PC<NH> &pc, ldouble *pc_lds, int p, Lane &C, PC<NH> &pcc)
 {
     C = L;
-    C.lane = (unsigned)p;
+    C.lane = 8u * (unsigned)p;
     C.b = (unsigned)__builtin_amdgcn_readlane((int)L.b, p);
     C.nobs = __builtin_amdgcn_readlane(L.nobs, p);
     C.h = bcast(L.h, p); C.hh = bcast(L.hh, p); C.h6 = bcast(L.h6, p);
@@ -1539,79 +1546,118 @@ DEV double from_lane_below(double v, double edge)
 // on, so after s steps the first s stages hold their true results, and a stage whose input
 // is true reproduces the same result in every later step.  After as many steps as there are
 // stages all of them are true; what the other lanes computed meanwhile is never used.
-template <int NH, bool ONE>
-__device__ __attribute__((noinline)) void coop_B0(Lane C, PC<NH> pc, const mpcx_opts *op, bool sp_have, int sp_mode,
-                                                  double sp_sigma_mu, double sp_alpha, int m_total, ldouble *ret)
+// LDS words of one wavefront behind the result slots of the sweeps: what a block of stages
+// hands to the next one (wave-uniform values, parked there so that they do not occupy
+// registers while the rows of the next block are computed)
+enum { CY_P = 0, CY_PV = 15, CY_VX = 20, CY_QPI = 25, CY_NORM = 30, CY_N = 35 };
+
+DEV void lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// one block of 64 consecutive stages (k0 .. k0+63) of sweep B0; what the block above handed
+// down, and the running reductions, are read from and left in the carry words
+template <int NH>
+__device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const mpcx_opts *op, bool sp_have, int sp_mode,
+                                                        double sp_sigma_mu, double sp_alpha, int k0, ldouble *ret)
 {
     const mpcx_opts &o = *op;
     Step sp;
     sp.have = sp_have; sp.mode = sp_mode; sp.sigma_mu = sp_sigma_mu; sp.alpha = sp_alpha;
     const int N = C.N;
     const int j = (int)threadIdx.x;
-    coop_sync();
-    // what the block of stages above hands down: P, p of its lowest stage, and that stage's
-    // updated state and multiplier
-    double cP[15], cp[NX], cvx[NX], cqpi[NX];
+    ldouble *carry = ret - j + 5 * 64;      // same address in every lane
+    const int kj = k0 + j;
+    const Lane S = stage_lane(C, (unsigned)kj);
+    // the stage above supplies its updated state and multiplier: the lane above, or the
+    // lowest stage of the block above
+    double vx[NX], qpi[NX], vxn[NX], qpin[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { cp[i] = 0.0; cvx[i] = 0.0; cqpi[i] = 0.0; }
+    for (int i = 0; i < NX; ++i) { vx[i] = 0.0; qpi[i] = 0.0; }
+    if (kj <= N) stage_B0_peek<NH>(S, 0, sp, vx, qpi);
 #pragma unroll
-    for (int i = 0; i < 15; ++i) cP[i] = 0.0;
-    double ng = 0.0, nb = 0.0, nd = 0.0, nm = 0.0, sum = 0.0;
-    // blocks of 64 consecutive stages, the last block first (ONE: N < 64, a single block)
-    for (int k0 = ONE ? 0 : (N / 64) * 64; k0 >= 0; k0 -= 64) {
-        const int kj = k0 + j;
-        const Lane S = stage_lane(C, (unsigned)kj, true);
-        double vx[NX], qpi[NX], vxn[NX], qpin[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { vx[i] = 0.0; qpi[i] = 0.0; }
-        if (kj <= N) stage_B0_peek<NH>(S, 0, sp, vx, qpi);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            vxn[i] = from_lane_above(vx[i], cvx[i]);
-            qpin[i] = from_lane_above(qpi[i], cqpi[i]);
-            cvx[i] = bcast(vx[i], 0);
-            cqpi[i] = bcast(qpi[i], 0);
-        }
-        B0Out t = {};
-        const KR kr = {kj == 0, kj == N};
-        if (kj <= N) stage_B0_rows<NH, ANY>(S, o, pc, 0, sp, vxn, qpin, t, kr);
-        // reductions over the stages of the block, downwards
-        const int kend = (N - k0 < 63) ? N - k0 : 63;
-        for (int kk = kend; kk >= 0; --kk) {
-            ng = dmax(ng, bcast(t.ng, kk)); nb = dmax(nb, bcast(t.nb, kk));
-            nd = dmax(nd, bcast(t.nd, kk)); nm = dmax(nm, bcast(t.nm, kk));
-            sum = sum + bcast(t.ssum, kk);
-        }
-        // Riccati recursion down the lanes
-        double Po[15], po[NX];
-        RicOut ro = {};
-#pragma unroll
-        for (int i = 0; i < NX; ++i) po[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < 15; ++i) Po[i] = 0.0;
-        if (kj == N) stage_B0_ric<LAST>(S, t, Po, po, ro);
-        const int steps = (N - k0 < 64) ? N - k0 : 64;       // stages below N in this block
-        for (int s = 0; s < steps; ++s) {
-            double Pi[15], pi[NX];
-#pragma unroll
-            for (int i = 0; i < 15; ++i) Pi[i] = from_lane_above(Po[i], cP[i]);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) pi[i] = from_lane_above(po[i], cp[i]);
-            if (kj < N) {
-                stage_B0_ric<MID>(S, t, Pi, pi, ro);
-#pragma unroll
-                for (int i = 0; i < 15; ++i) Po[i] = Pi[i];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) po[i] = pi[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 15; ++i) cP[i] = bcast(Po[i], 0);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) cp[i] = bcast(po[i], 0);
-        if (kj <= N) store_ric<NH>(S, 0, kj < N, kj > 0, ro, Po);
+    for (int i = 0; i < NX; ++i) {
+        vxn[i] = from_lane_above(vx[i], carry[CY_VX + i]);
+        qpin[i] = from_lane_above(qpi[i], carry[CY_QPI + i]);
     }
+    lds_order();
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const double a = bcast(vx[i], 0), b = bcast(qpi[i], 0);
+        if (j == 0) { carry[CY_VX + i] = a; carry[CY_QPI + i] = b; }
+    }
+    B0Out t = {};
+    const KR kr = {kj == 0, kj == N};
+    if (kj <= N) stage_B0_rows<NH, ANY>(S, o, pc, 0, sp, vxn, qpin, t, kr);
+    // reductions over the stages of the block, downwards
+    const int kend = (N - k0 < 63) ? N - k0 : 63;
+    lds_order();
+    double ng = carry[CY_NORM + 0], nb = carry[CY_NORM + 1], nd = carry[CY_NORM + 2], nm = carry[CY_NORM + 3],
+           sum = carry[CY_NORM + 4];
+    for (int kk = kend; kk >= 0; --kk) {
+        ng = dmax(ng, bcast(t.ng, kk)); nb = dmax(nb, bcast(t.nb, kk));
+        nd = dmax(nd, bcast(t.nd, kk)); nm = dmax(nm, bcast(t.nm, kk));
+        sum = sum + bcast(t.ssum, kk);
+    }
+    // Riccati recursion down the lanes; cP, cp: P and p of the lowest stage of the block above
+    double cP[15], cp[NX];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) cP[i] = carry[CY_P + i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) cp[i] = carry[CY_PV + i];
+    lds_order();
+    if (j == 0) {
+        carry[CY_NORM + 0] = ng; carry[CY_NORM + 1] = nb; carry[CY_NORM + 2] = nd; carry[CY_NORM + 3] = nm;
+        carry[CY_NORM + 4] = sum;
+    }
+    double Po[15], po[NX];
+    RicOut ro = {};
+#pragma unroll
+    for (int i = 0; i < NX; ++i) po[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) Po[i] = 0.0;
+    if (kj == N) stage_B0_ric<LAST>(S, t, Po, po, ro);
+    const int steps = (N - k0 < 64) ? N - k0 : 64;       // stages below N in this block
+    for (int s = 0; s < steps; ++s) {
+        double Pi[15], pi[NX];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) Pi[i] = from_lane_above(Po[i], cP[i]);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) pi[i] = from_lane_above(po[i], cp[i]);
+        if (kj < N) {
+            stage_B0_ric<MID>(S, t, Pi, pi, ro);
+#pragma unroll
+            for (int i = 0; i < 15; ++i) Po[i] = Pi[i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) po[i] = pi[i];
+        }
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) carry[CY_P + i] = Po[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) carry[CY_PV + i] = po[i];
+    }
+    lds_order();
+    if (kj <= N) store_ric<NH>(S, 0, kj < N, kj > 0, ro, Po);
+}
+
+template <int NH>
+DEV void coop_B0(const Lane &C, const PC<NH> &pc, const mpcx_opts *op, const Step &sp, int m_total, ldouble *ret)
+{
+    const int N = C.N;
+    ldouble *carry = ret - threadIdx.x + 5 * 64;
     coop_sync();
+    if (threadIdx.x < CY_N) carry[threadIdx.x] = 0.0;
+    lds_order();
+    // blocks of 64 consecutive stages, the last block first
+    for (int k0 = (N / 64) * 64; k0 >= 0; k0 -= 64)
+        coop_B0_block<NH>(C, pc, op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, k0, ret);
+    coop_sync();
+    const double ng = carry[CY_NORM + 0], nb = carry[CY_NORM + 1], nd = carry[CY_NORM + 2], nm = carry[CY_NORM + 3],
+                 sum = carry[CY_NORM + 4];
     ret[0 * 64] = ng; ret[1 * 64] = nb; ret[2 * 64] = nd; ret[3 * 64] = nm;
     ret[4 * 64] = sum / (double)m_total;
 }
@@ -1628,7 +1674,7 @@ __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_
     for (int i = 0; i < NX; ++i) { c1[i] = 0.0; c2[i] = 0.0; }
     for (int k0 = ONE ? 0 : (N / 64) * 64; k0 >= 0; k0 -= 64) {
         const int kj = k0 + j;
-        const Lane S = stage_lane(C, (unsigned)kj, true);
+        const Lane S = stage_lane(C, (unsigned)kj);
         BsOut t = {};
         const KR kr = {kj == 0, kj == N};
         if (kj <= N) stage_Bs_rows<NH, ANY>(S, o, pc, 0, sigma_mu, t, kr);
@@ -1673,7 +1719,7 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
     double alpha[2] = {1.0, 1.0}, s1 = 0.0, s2 = 0.0;
     for (int k0 = 0; ONE ? (k0 == 0) : (k0 <= N); k0 += 64) {
         const int kj = k0 + j;
-        const Lane S = stage_lane(C, (unsigned)kj, true);
+        const Lane S = stage_lane(C, (unsigned)kj);
         // what the recursion needs of this lane's stage
         AB ab = {};
         double rb[NX], kg[NU][NX], kv[NS][NU];
@@ -1748,7 +1794,7 @@ __device__ __attribute__((noinline)) void coop_L(Lane C, PC<NH> pc, const mpcx_o
     LAcc tot = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (int k0 = 0; ONE ? (k0 == 0) : (k0 <= N); k0 += 64) {
         const int kj = k0 + j;
-        const Lane S = stage_lane(C, (unsigned)kj, true);
+        const Lane S = stage_lane(C, (unsigned)kj);
         // everything a lane reads of its own and of the next stage, before any lane stores
         double xk[NX], pik[NX], nxt[3 * NX];
 #pragma unroll
@@ -1844,7 +1890,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     const unsigned B = (unsigned)in.B;
     const size_t wave_doubles = (size_t)(N + 1) * M::F * 64;
 
-    __shared__ double pc_lds[(PCN<NH>::N + 5) * 64];
+    __shared__ double pc_lds[(PCN<NH>::N + 6) * 64];      // constants, 5 result slots, carry words
     PC<NH> pc;
     pc.p = (ldouble *)pc_lds + threadIdx.x;
     pc.lmk = 0.0;
@@ -1854,8 +1900,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     L.wave = (gdouble *)workspace + (size_t)blockIdx.x * wave_doubles;
     L.pdata = (const gdouble *)in.pdata;
     L.B = (size_t)in.B;
-    L.lane = threadIdx.x;
-    L.writer = true;
+    L.lane = 8u * threadIdx.x;
     L.b = 0;
     L.N = N;
     L.F = M::F;
@@ -2012,8 +2057,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                 const int mt = __builtin_amdgcn_readlane(m_total, p);
                 int qit = __builtin_amdgcn_readlane(qp_it, p);
                 int n_state = LS_QP, n_status = -1, add_total = 0, add_sqp = 0;
-                if (N < 64) coop_B0<NH, true>(C, pcc, op, s.have, s.mode, s.sigma_mu, s.alpha, mt, ret);
-                else coop_B0<NH, false>(C, pcc, op, s.have, s.mode, s.sigma_mu, s.alpha, mt, ret);
+                coop_B0<NH>(C, pcc, op, s, mt, ret);
                 STAMP(12, true);
                 const double Rg = uniform(ret[0 * 64]), Rb = uniform(ret[1 * 64]), Rd = uniform(ret[2 * 64]),
                              Rm = uniform(ret[3 * 64]), mu = uniform(ret[4 * 64]);
