@@ -1874,15 +1874,11 @@ enum LaneState {
 #ifndef MPCX_SERVICE_MIN
 #define MPCX_SERVICE_MIN 8
 #endif
-// With this many problems or fewer in the interior point the wavefront takes them one at a
-// time in single-problem mode.
-#ifndef MPCX_COOP_MAX
-#define MPCX_COOP_MAX 4
-#endif
-
+// (coop_max: with this many problems or fewer in progress the wavefront takes them one at a
+// time in single-problem mode.)
 template <int NH>
 __global__ void __launch_bounds__(64)
-mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes)
+mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max)
 {
     const mpcx_opts &o = *op;
     typedef Map<NH> M;
@@ -1921,7 +1917,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         const bool wants = (state == LS_OUT) || (state == LS_FETCH) || (state == LS_LIN);
         const int n_wants = __popcll(__ballot(wants));
         const int n_qp = __popcll(__ballot(state == LS_QP));
-        const bool few = n_qp <= MPCX_COOP_MAX;     // single-problem mode ahead
+        const bool few = n_qp <= coop_max;     // single-problem mode ahead
         if (n_wants >= MPCX_SERVICE_MIN || n_qp == 0 || (few && n_wants > 0)) {
             const bool st_e = (state == LS_OUT);
             if (state == LS_OUT) {
@@ -1992,7 +1988,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             const bool st_b = (state == LS_LIN);
             // few problems in the wavefront: sweep L of each with a lane per stage
             const unsigned long long lin_mask = __ballot(state == LS_LIN);
-            const bool coop_lin = !o.rti && (__popcll(lin_mask) + n_qp <= MPCX_COOP_MAX);
+            const bool coop_lin = !o.rti && (__popcll(lin_mask) + n_qp <= coop_max);
             if (coop_lin) {
                 for (unsigned long long rest = lin_mask; rest != 0; rest &= rest - 1) {
                     const int p = __ffsll((long long)rest) - 1;
@@ -2043,7 +2039,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
 
         // ---- few problems left: one interior-point iteration of each, the wavefront on one problem
         const unsigned long long qp_mask = __ballot(state == LS_QP);
-        if (__popcll(qp_mask) <= MPCX_COOP_MAX) {
+        if (__popcll(qp_mask) <= coop_max) {
             for (unsigned long long rest = qp_mask; rest != 0; rest &= rest - 1) {
                 const int p = __ffsll((long long)rest) - 1;
                 Lane C;
@@ -2200,8 +2196,9 @@ size_t mpcx_stage_doubles(int nh)
 }
 
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
-                           double *workspace, int n_waves, int lanes, hipStream_t stream)
+                           double *workspace, int n_waves, int lanes, int coop_max, hipStream_t stream)
 {
+    if (coop_max < 0 || coop_max > 64) return hipErrorInvalidValue;
     if (lanes < 1 || lanes > 64 || n_waves < 1) return hipErrorInvalidValue;
     // workspace header (512 bytes): problem counter at byte 0, the options at byte 256
     static_assert(sizeof(mpcx_opts) <= 256, "options must fit the workspace header");
@@ -2215,12 +2212,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     if (e != hipSuccess) return e;
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max); break;
 #else
     default: return hipErrorInvalidValue;
 #endif
