@@ -42,7 +42,8 @@ constexpr int kWavesPerCU = 4;    // resident wavefronts per CU the kernel's reg
 // (64 problems each, refilled from the queue).  Small ones are spread thin, down to one
 // problem per wavefront, because a wavefront with few problems finishes each of them
 // sooner; the spread is limited so that the workspace stays below kWorkspaceTarget.
-struct Plan { int waves, lanes, coop_max; };
+struct Plan { int waves, lanes, coop_max, lin_max; };
+constexpr int kLinMax = 0;
 constexpr int kCoopMax = 8;     // problems per wavefront up to which the single-problem sweeps pay
 constexpr size_t kWorkspaceTarget = (size_t)8 << 30;
 
@@ -66,6 +67,11 @@ Plan plan_for(int B, int N)
     if (const char *e = std::getenv("MPCX_COOP_MAX")) {      // diagnostic knob, 0 switches the mode off
         const int v = std::atoi(e);
         if (v >= 0 && v <= 64) p.coop_max = v;
+    }
+    p.lin_max = kLinMax;
+    if (const char *e = std::getenv("MPCX_LIN_MAX")) {
+        const int v = std::atoi(e);
+        if (v >= 0 && v <= 64) p.lin_max = v;
     }
     p.waves = (B + p.lanes - 1) / p.lanes;
     if (p.waves > (int)cap) p.waves = (int)cap;
@@ -158,7 +164,7 @@ int mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts, mpcx_re
     if (!workspace || workspace_bytes < need)
         return fail(MPCX_E_BADARG, "workspace too small: %zu bytes given, %zu needed", workspace_bytes, need);
     if ((uintptr_t)workspace % 256 != 0) return fail(MPCX_E_BADARG, "workspace not 256-byte aligned");
-    HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(workspace), waves_to_launch(plan), plan.lanes, plan.coop_max,
+    HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(workspace), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max,
                             static_cast<hipStream_t>(stream)));
     return 0;
 }
@@ -219,7 +225,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     dout.cost = d_co.as<double>();
     dout.res = d_re.as<double>();
 
-    HIP_TRY(mpcx_launch_sqp(nh, din, o, dout, d_ws.as<double>(), waves_to_launch(plan), plan.lanes, plan.coop_max, nullptr));
+    HIP_TRY(mpcx_launch_sqp(nh, din, o, dout, d_ws.as<double>(), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, nullptr));
     HIP_TRY(hipDeviceSynchronize());
 
     HIP_TRY(hipMemcpy(out->X, d_X.p, n_X * 8, hipMemcpyDeviceToHost));

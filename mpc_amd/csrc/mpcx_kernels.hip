@@ -49,6 +49,13 @@
 typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(3))) double ldouble;
 
+// The reciprocals of the slacks are needed in all four sweeps of an interior-point iteration.
+// 1: computed once per iteration and kept in the workspace; 0: recomputed where needed, which
+// trades 72 divisions per stage and iteration for 90 of the ~615 doubles of workspace traffic.
+#ifndef MPCX_STORE_RECIP
+#define MPCX_STORE_RECIP 0
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -67,9 +74,10 @@ struct Map {
     static constexpr int LAMU = LAML + R;      // R
     static constexpr int TL = LAMU + R;        // R  slacks
     static constexpr int TU = TL + R;          // R
-    static constexpr int TIL = TU + R;         // R  1 / slack
-    static constexpr int TIU = TIL + R;        // R
-    static constexpr int RG = TIU + R;         // 7  stationarity residual
+    static constexpr int RS = MPCX_STORE_RECIP ? R : 0;
+    static constexpr int TIL = TU + R;         // RS 1 / slack (only if stored, see MPCX_STORE_RECIP)
+    static constexpr int TIU = TIL + RS;       // RS
+    static constexpr int RG = TIU + RS;        // 7  stationarity residual
     static constexpr int RB = RG + 7;          // 5  dynamics residual
     static constexpr int PRB = RB + 5;         // 5  P(k+1) * rb
     static constexpr int K = PRB + 5;          // 10 feedback gain, row-major [2][5]
@@ -666,8 +674,10 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
         stw(L, k, M::TU + r, tu);
         stw(L, k, M::LAML + r, mu0 / tl);
         stw(L, k, M::LAMU + r, mu0 / tu);
-        stw(L, k, M::TIL + r, 1.0 / tl);
-        stw(L, k, M::TIU + r, 1.0 / tu);
+        if (MPCX_STORE_RECIP) {
+            stw(L, k, M::TIL + r, 1.0 / tl);
+            stw(L, k, M::TIU + r, 1.0 / tu);
+        }
     }
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
@@ -782,8 +792,10 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
         lu[r] = ldw(L, k, M::LAMU + r);
         tl[r] = ldw(L, k, M::TL + r);
         tu[r] = ldw(L, k, M::TU + r);
-        til_[r] = ldw(L, k, M::TIL + r);
-        tiu_[r] = ldw(L, k, M::TIU + r);
+        if (MPCX_STORE_RECIP) {
+            til_[r] = ldw(L, k, M::TIL + r);
+            tiu_[r] = ldw(L, k, M::TIU + r);
+        }
     }
     AB ab = {};
     double bv[NX];
@@ -843,7 +855,7 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
             double jvo = jdot(r, jx, jy, vo);
             double rdl = (dlo - jvo) + t_l;
             double rdu = (jvo - dup) + t_u;
-            double til = til_[r], tiu = tiu_[r];
+            double til = MPCX_STORE_RECIP ? til_[r] : 1.0 / t_l, tiu = MPCX_STORE_RECIP ? tiu_[r] : 1.0 / t_u;
             double jda = jdot(r, jx, jy, dva);
             double rml, rmu;
             row_rm(sp.mode, sp.sigma_mu, jda, l_l, l_u, t_l, t_u, til, tiu, rdl, rdu, rml, rmu);
@@ -880,8 +892,10 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
         ssum = pr ? sum : ssum;
         // affine right-hand side and barrier Hessian
         double til = 1.0 / t_l, tiu = 1.0 / t_u;
-        stw(L, k, M::TIL + r, til);
-        stw(L, k, M::TIU + r, tiu);
+        if (MPCX_STORE_RECIP) {
+            stw(L, k, M::TIL + r, til);
+            stw(L, k, M::TIU + r, tiu);
+        }
         double ql = fma(-l_l, rdl, ml) * til;
         double qu = fma(-l_u, rdu, mu_) * tiu;
         qrow[r] = ql - qu;
@@ -1144,8 +1158,10 @@ DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
         lu[r] = ldw(L, k, M::LAMU + r);
         tl[r] = ldw(L, k, M::TL + r);
         tu[r] = ldw(L, k, M::TU + r);
-        til_[r] = ldw(L, k, M::TIL + r);
-        tiu_[r] = ldw(L, k, M::TIU + r);
+        if (MPCX_STORE_RECIP) {
+            til_[r] = ldw(L, k, M::TIL + r);
+            tiu_[r] = ldw(L, k, M::TIU + r);
+        }
     }
     out.ab = AB{};
     out.l10 = 0.0; out.d0 = 1.0; out.d1 = 1.0;
@@ -1177,7 +1193,7 @@ DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
         double jv = jdot(r, jx, jy, v);
         double rdl = (dlo - jv) + tl[r];
         double rdu = (jv - dup) + tu[r];
-        double til = til_[r], tiu = tiu_[r];
+        double til = MPCX_STORE_RECIP ? til_[r] : 1.0 / tl[r], tiu = MPCX_STORE_RECIP ? tiu_[r] : 1.0 / tu[r];
         double jda = jdot(r, jx, jy, dva);
         // complementarity targets: corrector and centring-only
         const double ml = ll[r] * tl[r], mu_ = lu[r] * tu[r];
@@ -1320,8 +1336,10 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, dou
         lu[r] = ldw(L, k, M::LAMU + r);
         tl[r] = ldw(L, k, M::TL + r);
         tu[r] = ldw(L, k, M::TU + r);
-        til_[r] = ldw(L, k, M::TIL + r);
-        tiu_[r] = ldw(L, k, M::TIU + r);
+        if (MPCX_STORE_RECIP) {
+            til_[r] = ldw(L, k, M::TIL + r);
+            tiu_[r] = ldw(L, k, M::TIU + r);
+        }
     }
     AB ab = {};
     double rb[NX], kv[NS][NU], kg[NU][NX], pv[NS][NX], Pk[15];
@@ -1385,7 +1403,7 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, dou
         double jv = jdot(r, jx, jy, v);
         double rdl = (dlo - jv) + tl[r];
         double rdu = (jv - dup) + tu[r];
-        double til = til_[r], tiu = tiu_[r];
+        double til = MPCX_STORE_RECIP ? til_[r] : 1.0 / tl[r], tiu = MPCX_STORE_RECIP ? tiu_[r] : 1.0 / tu[r];
         const double ml = ll[r] * tl[r], mu_ = lu[r] * tu[r];
         double rml[NS], rmu[NS];
         if (NS == 1) { rml[0] = ml; rmu[0] = mu_; }
@@ -1878,7 +1896,7 @@ enum LaneState {
 // time in single-problem mode.)
 template <int NH>
 __global__ void __launch_bounds__(64)
-mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max)
+mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max)
 {
     const mpcx_opts &o = *op;
     typedef Map<NH> M;
@@ -1905,7 +1923,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
 
     int state = ((int)threadIdx.x < lanes) ? LS_FETCH : LS_DONE;
     int status = MPCX_MAXITER, sqp_it = 0, qp_it = 0, qp_total = 0, m_total = 0;
-    bool first = true;
+    bool first = true, fresh = false;
     double res[4] = {0.0, 0.0, 0.0, 0.0};
     double cost = 0.0;
     Step sp;
@@ -1920,17 +1938,33 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         const bool few = n_qp <= coop_max;     // single-problem mode ahead
         if (n_wants >= MPCX_SERVICE_MIN || n_qp == 0 || (few && n_wants > 0)) {
             const bool st_e = (state == LS_OUT);
-            if (state == LS_OUT) {
-                const size_t b = L.b;
-                for (int k = 0; k <= N; ++k) {
+            // the trajectory of each finished problem is copied out by the whole wavefront, a lane
+            // per stage: one round trip to memory instead of one per stage
+            const unsigned long long out_mask = __ballot(state == LS_OUT);
+            if (out_mask != 0) coop_sync();
+            for (unsigned long long rest = out_mask; rest != 0; rest &= rest - 1) {
+                const int p = __ffsll((long long)rest) - 1;
+                const size_t b = (unsigned)__builtin_amdgcn_readlane((int)L.b, p);
+                Lane C = L;
+                C.lane = 8u * (unsigned)p;
+                for (int k0 = 0; k0 <= N; k0 += 64) {
+                    const int kj = k0 + (int)threadIdx.x;
+                    if (kj > N) continue;
+                    const Lane S = stage_lane(C, (unsigned)kj);
+                    double xo[NX], uo[NU] = {0.0, 0.0};
 #pragma unroll
-                    for (int i = 0; i < NX; ++i)
-                        out.X[(b * (size_t)(N + 1) + k) * NX + i] = ldw(L, k, M::X + i);
-                    if (k < N) {
-                        out.U[(b * (size_t)N + k) * NU + 0] = ldw(L, k, M::U + 0);
-                        out.U[(b * (size_t)N + k) * NU + 1] = ldw(L, k, M::U + 1);
+                    for (int i = 0; i < NX; ++i) xo[i] = ldw(S, 0, M::X + i);
+                    if (kj < N) { uo[0] = ldw(S, 0, M::U + 0); uo[1] = ldw(S, 0, M::U + 1); }
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) out.X[(b * (size_t)(N + 1) + kj) * NX + i] = xo[i];
+                    if (kj < N) {
+                        out.U[(b * (size_t)N + kj) * NU + 0] = uo[0];
+                        out.U[(b * (size_t)N + kj) * NU + 1] = uo[1];
                     }
                 }
+            }
+            if (state == LS_OUT) {
+                const size_t b = L.b;
                 out.status[b] = status;
                 out.sqp_iter[b] = sqp_it;
                 out.qp_iter[b] = qp_total;
@@ -1962,33 +1996,50 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                         fill_pc<NH>(L, o, pc);
                         // row sides: stage 0 has the 2 input rows, stages 1..N-1 all rows, stage N 7 rows
                         m_total = 2 * (NU + (N - 1) * (9 + nobs) + 7);
-                        for (int k = 0; k <= N; ++k) {
-#pragma unroll
-                            for (int i = 0; i < NX; ++i) {
-                                stw(L, k, M::X + i, in.xguess[((size_t)k * NX + i) * L.B + b]);
-                                stw(L, k, M::QPI + i, 0.0);
-                            }
-                            stw(L, k, M::U + 0, 0.0);
-                            stw(L, k, M::U + 1, 0.0);
-#pragma unroll
-                            for (int r = 0; r < M::R; ++r) {
-                                stw(L, k, M::LAML + r, 0.0);
-                                stw(L, k, M::LAMU + r, 0.0);
-                            }
-                        }
                         status = MPCX_MAXITER;
                         sqp_it = 0;
                         qp_total = 0;
                         first = true;
                         state = LS_LIN;
+                        fresh = true;
                     }
                 }
             }
+            // the initial iterate of each new problem is laid down by the whole wavefront, a lane per stage
+            const unsigned long long new_mask = __ballot(fresh);
+            fresh = false;
+            for (unsigned long long rest = new_mask; rest != 0; rest &= rest - 1) {
+                const int p = __ffsll((long long)rest) - 1;
+                const size_t b = (unsigned)__builtin_amdgcn_readlane((int)L.b, p);
+                Lane C = L;
+                C.lane = 8u * (unsigned)p;
+                for (int k0 = 0; k0 <= N; k0 += 64) {
+                    const int kj = k0 + (int)threadIdx.x;
+                    if (kj > N) continue;
+                    const Lane S = stage_lane(C, (unsigned)kj);
+                    double xg[NX];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) xg[i] = in.xguess[((size_t)kj * NX + i) * L.B + b];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {
+                        stw(S, 0, M::X + i, xg[i]);
+                        stw(S, 0, M::QPI + i, 0.0);
+                    }
+                    stw(S, 0, M::U + 0, 0.0);
+                    stw(S, 0, M::U + 1, 0.0);
+#pragma unroll
+                    for (int r = 0; r < M::R; ++r) {
+                        stw(S, 0, M::LAML + r, 0.0);
+                        stw(S, 0, M::LAMU + r, 0.0);
+                    }
+                }
+            }
+            if (new_mask != 0) coop_sync();
             STAMP(0, st_a);
             const bool st_b = (state == LS_LIN);
             // few problems in the wavefront: sweep L of each with a lane per stage
             const unsigned long long lin_mask = __ballot(state == LS_LIN);
-            const bool coop_lin = !o.rti && (__popcll(lin_mask) + n_qp <= coop_max);
+            const bool coop_lin = !o.rti && ((__popcll(lin_mask) + n_qp <= coop_max) || (__popcll(lin_mask) <= lin_max));
             if (coop_lin) {
                 for (unsigned long long rest = lin_mask; rest != 0; rest &= rest - 1) {
                     const int p = __ffsll((long long)rest) - 1;
@@ -2196,7 +2247,7 @@ size_t mpcx_stage_doubles(int nh)
 }
 
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
-                           double *workspace, int n_waves, int lanes, int coop_max, hipStream_t stream)
+                           double *workspace, int n_waves, int lanes, int coop_max, int lin_max, hipStream_t stream)
 {
     if (coop_max < 0 || coop_max > 64) return hipErrorInvalidValue;
     if (lanes < 1 || lanes > 64 || n_waves < 1) return hipErrorInvalidValue;
@@ -2212,12 +2263,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     if (e != hipSuccess) return e;
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max); break;
 #else
     default: return hipErrorInvalidValue;
 #endif
