@@ -33,6 +33,7 @@
 // a CPU program that performs the dense sequence gets the same bits.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mpcx.h"
 #include "mpcx_kernels.h"
@@ -1890,13 +1891,13 @@ enum LaneState {
 // Write-out, fetch and sweep L ("service") run with few lanes each, so they are held
 // back until this many lanes wait for them (or no lane has interior-point work).
 #ifndef MPCX_SERVICE_MIN
-#define MPCX_SERVICE_MIN 8
+#define MPCX_SERVICE_MIN 4
 #endif
 // (coop_max: with this many problems or fewer in progress the wavefront takes them one at a
 // time in single-problem mode.)
 template <int NH>
 __global__ void __launch_bounds__(64)
-mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max)
+mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min)
 {
     const mpcx_opts &o = *op;
     typedef Map<NH> M;
@@ -1936,7 +1937,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         const int n_wants = __popcll(__ballot(wants));
         const int n_qp = __popcll(__ballot(state == LS_QP));
         const bool few = n_qp <= coop_max;     // single-problem mode ahead
-        if (n_wants >= MPCX_SERVICE_MIN || n_qp == 0 || (few && n_wants > 0)) {
+        if (n_wants >= svc_min || n_qp == 0 || (few && n_wants > 0)) {
             const bool st_e = (state == LS_OUT);
             // the trajectory of each finished problem is copied out by the whole wavefront, a lane
             // per stage: one round trip to memory instead of one per stage
@@ -2249,6 +2250,8 @@ size_t mpcx_stage_doubles(int nh)
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
                            double *workspace, int n_waves, int lanes, int coop_max, int lin_max, hipStream_t stream)
 {
+    int svc_min = MPCX_SERVICE_MIN;
+    if (const char *e = getenv("MPCX_SVC_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) svc_min = v; }
     if (coop_max < 0 || coop_max > 64) return hipErrorInvalidValue;
     if (lanes < 1 || lanes > 64 || n_waves < 1) return hipErrorInvalidValue;
     // workspace header (512 bytes): problem counter at byte 0, the options at byte 256
@@ -2263,12 +2266,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     if (e != hipSuccess) return e;
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min); break;
 #else
     default: return hipErrorInvalidValue;
 #endif
