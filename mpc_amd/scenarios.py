@@ -7,6 +7,10 @@ solutions and are solved as one batch; the stitching, the time offsets and the
 abort-at-first-failure rule are the reference's.  Plot output (:57-65,
 :151-200) is presentation and is not rebuilt.
 """
+import os
+import sys
+import types
+
 import numpy as np
 
 from .core_solver import EgoConfig, SimConfig, generate_controls_batch
@@ -104,3 +108,87 @@ def results_all_entry(scenario, results, ego):
             'controls': results['u'], 'status': results['status'],
             'start_state': scenario['start_state'], 'goal_state': scenario['goal_state'],
             'ego_config': ego}
+
+
+# ---------------------------------------------------------------------------
+# result files (reference src/scenarios.py:9-16, :289-383)
+# ---------------------------------------------------------------------------
+def create_docs_dir(base=None):
+    """``<base>/docs`` (created if missing); base defaults to the working directory."""
+    docs_dir = os.path.join(base if base is not None else os.getcwd(), "docs")
+    os.makedirs(docs_dir, exist_ok=True)
+    return docs_dir
+
+
+class _PickledAs:
+    """While active, EgoConfig / SimConfig pickle under module name ``module``.
+
+    The reference's scripts import ``core_solver`` as a top-level module, so the
+    object arrays it saves embed ``core_solver.EgoConfig``; its loaders
+    (create_animation.py:10-14) unpickle against that name.  Files written under
+    this alias therefore load there, the instance attributes being the same.
+    Nothing is aliased when a real module of that name is already imported.
+    """
+
+    def __init__(self, module="core_solver"):
+        self.module = module
+        self.active = False
+
+    def __enter__(self):
+        from . import core_solver as cs
+        if self.module and self.module not in sys.modules:
+            alias = types.ModuleType(self.module)
+            alias.EgoConfig, alias.SimConfig = cs.EgoConfig, cs.SimConfig
+            sys.modules[self.module] = alias
+            self._old = (cs.EgoConfig.__module__, cs.SimConfig.__module__)
+            cs.EgoConfig.__module__ = cs.SimConfig.__module__ = self.module
+            self.active = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            from . import core_solver as cs
+            cs.EgoConfig.__module__, cs.SimConfig.__module__ = self._old
+            del sys.modules[self.module]
+        return False
+
+
+def save_results(path, obj, pickle_module="core_solver"):
+    """``np.save`` of a result dict / list as the reference writes them (object array)."""
+    with _PickledAs(pickle_module):
+        np.save(path, obj)
+    return path
+
+
+def main(docs_dir=None, run_individual_scenarios=False, run_sequential_path=True,
+         opts=None, device=0, solver=None):
+    """The reference's ``__main__`` block (:289-383) without the plots: runs the
+    selected drivers and writes ``all_results.npy``, ``sequential_path_results.npy``
+    and ``sequential_all_results.npy`` into ``docs_dir``.  Returns the paths written."""
+    docs_dir = docs_dir or create_docs_dir()
+    written = {}
+    if run_individual_scenarios:
+        results_all = []
+        for scenario, (results, ego, ok) in zip(scenarios, run_scenarios(scenarios, opts, device, solver)):
+            if ok:
+                results_all.append(results_all_entry(scenario, results, ego))
+            else:
+                print(f"Failed to solve {scenario['name']} scenario")
+        if results_all:
+            written['all_results'] = save_results(os.path.join(docs_dir, "all_results.npy"), results_all)
+    if run_sequential_path:
+        combined, ok = run_sequential_planning(sequential_segments, name="A_to_F_Path",
+                                               opts=opts, device=device, solver=solver)
+        if ok:
+            written['sequential_path_results'] = save_results(
+                os.path.join(docs_dir, "sequential_path_results.npy"), combined)
+            results_all = [{'name': "Sequential_A_to_F", 'trajectory': combined['x'], 'time': combined['t'],
+                            'controls': combined['u'], 'status': combined['status'],
+                            'start_state': sequential_segments[0]['start_state'],
+                            'goal_state': sequential_segments[-1]['goal_state'],
+                            'segments': combined['segments']}]
+            written['sequential_all_results'] = save_results(
+                os.path.join(docs_dir, "sequential_all_results.npy"), results_all)
+        else:
+            print("Sequential path planning failed.")
+    return written

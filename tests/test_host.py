@@ -166,3 +166,20 @@ def test_no_silent_cpu_fallback():
     with pytest.raises(_lib.MpcxError):
         generate_controls(e, s)
     assert find_path(e, s) is None             # find_path never raises (reference :559-562)
+
+
+def test_result_files_load_like_the_reference(oracle, tmp_path):
+    """Files written by scenarios.main load the way reference create_animation.py:10-14 loads
+    them (own files, so unpickling is safe) and embed EgoConfig under module name core_solver."""
+    import pickletools
+    from mpc_amd import scenarios as sc
+    written = sc.main(docs_dir=str(tmp_path), solver=oracle.solve_packed)
+    assert set(written) == {"sequential_path_results", "sequential_all_results"}
+    raw = open(written["sequential_path_results"], "rb").read()
+    assert b"core_solver" in raw and b"mpc_amd" not in raw
+    with sc._PickledAs("core_solver"):
+        combined = np.load(written["sequential_path_results"], allow_pickle=True).item()
+    assert combined["x"].shape == (1191, 5) and combined["u"].shape == (1186, 2)
+    assert combined["t"].shape == (1191,) and combined["status"] == 0
+    assert [s["name"] for s in combined["segments"]] == [s["name"] for s in sc.sequential_segments]
+    assert combined["segments"][0]["ego"].corridor_width == sc.sequential_segments[0].get("corridor_width", 2.0)
