@@ -72,7 +72,7 @@ def main():
     d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     assert d_ws.data_ptr() % 256 == 0
 
-    bs = _lib.MpcxBatch(B, N, d_pd.data_ptr(), d_no.data_ptr(), d_xg.data_ptr())
+    bs = _lib.MpcxBatch(B, N, d_pd.data_ptr(), d_no.data_ptr(), d_xg.data_ptr(), None)
     rs = _lib.MpcxResult(d_X.data_ptr(), d_U.data_ptr(), d_st.data_ptr(), d_si.data_ptr(),
                          d_qi.data_ptr(), d_co.data_ptr(), d_re.data_ptr())
     stream = torch.cuda.current_stream()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 100
+#define MPCX_VERSION 101
 
 #define MPCX_NX 5       /* state  [x, y, theta, v, delta]        (core_solver.py:131) */
 #define MPCX_NU 2       /* input  [acceleration, steering rate]  (core_solver.py:132) */
@@ -65,6 +65,9 @@ typedef struct mpcx_batch {
     const double  *pdata;   /* [MPCX_NFIELDS][B]                                      */
     const int32_t *n_obs;   /* [B], each 0..MPCX_MAX_OBS                              */
     const double  *xguess;  /* [N+1][5][B] initial state guess (core_solver.py:477-499) */
+    const double  *uguess;  /* [N][2][B] initial input guess, or NULL = zeros, which is what the
+                               reference starts from (it never sets "u"); used by receding-
+                               horizon callers that shift the previous solution              */
 } mpcx_batch;
 
 /* Per-problem status, acados numbering as seen by core_solver.py:502-507. */

@@ -18,7 +18,8 @@ c_int32_p = C.POINTER(C.c_int32)
 
 class MpcxBatch(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32),
-                ("pdata", C.c_void_p), ("n_obs", C.c_void_p), ("xguess", C.c_void_p)]
+                ("pdata", C.c_void_p), ("n_obs", C.c_void_p), ("xguess", C.c_void_p),
+                ("uguess", C.c_void_p)]
 
 
 class MpcxOpts(C.Structure):
@@ -109,8 +110,12 @@ def batch_struct(packed):
     assert packed.pdata.flags.c_contiguous and packed.pdata.dtype == np.float64
     assert packed.xguess.flags.c_contiguous and packed.xguess.dtype == np.float64
     assert packed.n_obs.flags.c_contiguous and packed.n_obs.dtype == np.int32
+    ug = getattr(packed, "uguess", None)
+    if ug is not None:
+        assert ug.flags.c_contiguous and ug.dtype == np.float64 and ug.shape == (packed.N, 2, packed.B)
     return MpcxBatch(packed.B, packed.N, packed.pdata.ctypes.data,
-                     packed.n_obs.ctypes.data, packed.xguess.ctypes.data)
+                     packed.n_obs.ctypes.data, packed.xguess.ctypes.data,
+                     ug.ctypes.data if ug is not None else None)
 
 
 def result_struct(out):

@@ -45,13 +45,15 @@ class PackedBatch:
     n_obs: np.ndarray    # int32 [B]
     xguess: np.ndarray   # float64 [N+1, 5, B]
     duration: float = 0.0
+    uguess: np.ndarray = None    # float64 [N, 2, B] or None = zeros (the reference's start)
 
     def slice(self, lo, hi):
         return PackedBatch(hi - lo, self.N,
                            np.ascontiguousarray(self.pdata[:, lo:hi]),
                            np.ascontiguousarray(self.n_obs[lo:hi]),
                            np.ascontiguousarray(self.xguess[:, :, lo:hi]),
-                           self.duration)
+                           self.duration,
+                           None if self.uguess is None else np.ascontiguousarray(self.uguess[:, :, lo:hi]))
 
 
 # ---------------------------------------------------------------------------

@@ -196,7 +196,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     const Plan plan = plan_for(in->B, in->N);
     const size_t ws_bytes = 512 + (size_t)plan.waves * (N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
 
-    DevBuf d_pd, d_no, d_xg, d_X, d_U, d_st, d_si, d_qi, d_co, d_re, d_ws;
+    DevBuf d_pd, d_no, d_xg, d_ug, d_X, d_U, d_st, d_si, d_qi, d_co, d_re, d_ws;
     if (d_pd.alloc(n_pd * 8) != hipSuccess || d_no.alloc(B * 4) != hipSuccess ||
         d_xg.alloc(n_xg * 8) != hipSuccess || d_X.alloc(n_X * 8) != hipSuccess ||
         d_U.alloc(n_U * 8) != hipSuccess || d_st.alloc(B * 4) != hipSuccess ||
@@ -210,12 +210,17 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     if (in->n_obs) HIP_TRY(hipMemcpy(d_no.p, in->n_obs, B * 4, hipMemcpyHostToDevice));
     else HIP_TRY(hipMemset(d_no.p, 0, B * 4));
     HIP_TRY(hipMemcpy(d_xg.p, in->xguess, n_xg * 8, hipMemcpyHostToDevice));
+    if (in->uguess) {
+        if (d_ug.alloc(n_U * 8) != hipSuccess) { (void)hipGetLastError(); return fail(MPCX_E_NOMEM, "device allocation failed"); }
+        HIP_TRY(hipMemcpy(d_ug.p, in->uguess, n_U * 8, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemset(d_st.p, 0xff, B * 4));
 
     mpcx_batch din = *in;
     din.pdata = d_pd.as<double>();
     din.n_obs = d_no.as<int32_t>();
     din.xguess = d_xg.as<double>();
+    din.uguess = in->uguess ? d_ug.as<double>() : nullptr;
     mpcx_result dout;
     dout.X = d_X.as<double>();
     dout.U = d_U.as<double>();

@@ -2026,8 +2026,13 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                         stw(S, 0, M::X + i, xg[i]);
                         stw(S, 0, M::QPI + i, 0.0);
                     }
-                    stw(S, 0, M::U + 0, 0.0);
-                    stw(S, 0, M::U + 1, 0.0);
+                    double ug[NU] = {0.0, 0.0};
+                    if (in.uguess && kj < N) {
+                        ug[0] = in.uguess[((size_t)kj * NU + 0) * L.B + b];
+                        ug[1] = in.uguess[((size_t)kj * NU + 1) * L.B + b];
+                    }
+                    stw(S, 0, M::U + 0, ug[0]);
+                    stw(S, 0, M::U + 1, ug[1]);
 #pragma unroll
                     for (int r = 0; r < M::R; ++r) {
                         stw(S, 0, M::LAML + r, 0.0);

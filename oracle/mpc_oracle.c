@@ -844,7 +844,6 @@ static void sqp_solve(const problem *pb, const mpcx_opts *o, stage *st, outcome 
     int status = MPCX_MAXITER, it = 0, qp_total = 0;
     real res[4] = {0.0, 0.0, 0.0, 0.0};
     for (int k = 0; k <= N; ++k) {
-        for (int c = 0; c < NU; ++c) st[k].u[c] = (real)0.0;
         for (int i = 0; i < NX; ++i) st[k].pi[i] = (real)0.0;
         for (int r = 0; r < MAXR; ++r) st[k].nl_l[r] = st[k].nl_u[r] = (real)0.0;
     }
@@ -973,6 +972,10 @@ int mpcx_oracle_solve_batch(const mpcx_batch *in, const mpcx_opts *o, mpcx_resul
                 for (int k = 0; k <= N; ++k)
                     for (int i = 0; i < NX; ++i)
                         st[k].x[i] = (real)in->xguess[((size_t)k * NX + i) * B + b];
+                for (int k = 0; k <= N; ++k)
+                    for (int c = 0; c < NU; ++c)
+                        st[k].u[c] = (k < N && in->uguess) ? (real)in->uguess[((size_t)k * NU + c) * B + b]
+                                                           : (real)0.0;
                 sqp_solve(&pb, o, st, &oc);
                 for (int k = 0; k <= N; ++k)
                     for (int i = 0; i < NX; ++i)

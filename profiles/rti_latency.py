@@ -1,0 +1,51 @@
+"""Tick latency of the receding-horizon RTI server on one GPU.
+
+Usage on the GPU box:  python profiles/rti_latency.py [vehicles] [ticks]
+Fleet: the first `vehicles` problems of the synthetic benchmark distribution that a full
+solve converges on, started from that solution.  A tick = one linearisation + one QP per
+vehicle, the plant step and the shift, timed with HIP events on the launch stream.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from mpc_amd import _lib  # noqa: E402
+from mpc_amd.rti import RtiServer  # noqa: E402
+from mpc_amd.synthetic import synthetic_batch  # noqa: E402
+
+V = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+TICKS = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+pool = synthetic_batch(int(V / 0.08) + 4096)
+t0 = time.time()
+full = _lib.solve_packed(pool)
+ok = np.nonzero(full["status"] == 0)[0][:V]
+assert ok.size == V, f"only {ok.size} feasible problems in the pool"
+pick = lambda a, ax: np.ascontiguousarray(np.take(a, ok, axis=ax))
+fleet = type(pool)(V, pool.N, pick(pool.pdata, 1), pick(pool.n_obs, 0), pick(pool.xguess, 2), pool.duration)
+srv = RtiServer(fleet, X=full["X"][ok], U=full["U"][ok])
+print(f"fleet of {V} vehicles ready ({time.time() - t0:.1f} s for the initial full solve of {pool.B})", flush=True)
+stream = torch.cuda.current_stream()
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(TICKS)]
+qp = []
+for i, (e0, e1) in enumerate(ev):
+    e0.record(stream)
+    srv.tick()
+    e1.record(stream)
+    if i % 100 == 99:
+        torch.cuda.synchronize()
+        qp.append(float(srv.qp_iter.double().mean()))
+        print(f"tick {i + 1}: mean IP iterations {qp[-1]:.1f}, status!=0: {int((srv.status != 0).sum())}", flush=True)
+torch.cuda.synchronize()
+ms = np.array([e0.elapsed_time(e1) for e0, e1 in ev])
+x0 = srv.pdata[0:5].t().cpu().numpy()
+d = np.hypot(x0[:, 0] - fleet.pdata[5], x0[:, 1] - fleet.pdata[6])
+print(json.dumps({"vehicles": V, "ticks": TICKS, "N": fleet.N,
+                  "tick_ms_p50": float(np.percentile(ms, 50)), "tick_ms_p99": float(np.percentile(ms, 99)),
+                  "tick_ms_max": float(ms.max()), "vehicle_ticks_per_s": V / (np.median(ms) * 1e-3),
+                  "mean_distance_to_goal_m": float(d.mean())}))

@@ -26,12 +26,12 @@ def test_exports_match_header():
             "mpcx_probe_sincos"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mpcx.h but not exported"
-    assert lib.mpcx_version() == 100
+    assert lib.mpcx_version() == 101
 
 
 def test_struct_layout_and_defaults():
     o = _lib.default_opts()
-    assert C.sizeof(_lib.MpcxOpts) == 136 and C.sizeof(_lib.MpcxBatch) == 32 and C.sizeof(_lib.MpcxResult) == 56
+    assert C.sizeof(_lib.MpcxOpts) == 136 and C.sizeof(_lib.MpcxBatch) == 40 and C.sizeof(_lib.MpcxResult) == 56
     assert (o.max_sqp_iter, o.max_qp_iter, o.tol_stat, o.lm) == (200, 50, 1e-3, 1e-2)   # core_solver.py:246-252
     assert (o.qp_tol_comp, o.mu0, o.thr0, o.cond_pred_corr, o.rti, o.max_obs) == (1e-3, 10.0, 0.1, 1, 0, -1)
 

@@ -10,6 +10,8 @@ import ctypes as C
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  first, so that the process has ONE HIP runtime (torch ships its own; the
+              # receding-horizon test below shares device memory between torch and libmpcx)
 
 from mpc_amd import _lib
 from mpc_amd.batch import pack_problems
@@ -104,3 +106,39 @@ def test_sweep_modes_match_oracle(oracle, monkeypatch, duration, lanes):
     gpu = _lib.solve_packed(packed)
     ref = oracle.solve_packed(packed)
     cases.assert_same_solution(gpu, ref, f"N={packed.N} lanes={lanes}")
+
+
+def test_rti_server_matches_oracle(oracle):
+    """Three receding-horizon ticks of a fleet: what the device solves each tick equals the
+    oracle's one-iteration (rti) solve of the same tick inputs, bit for bit; the shift and the
+    plant step move the fleet towards the goal."""
+    from mpc_amd.rti import RtiServer
+    packed = synthetic_batch(4096)
+    full = _lib.solve_packed(packed)
+    ok = np.nonzero(full["status"] == 0)[0][:300]
+    assert ok.size == 300
+    sub = packed.slice(0, packed.B)
+    pick = lambda a, ax: np.ascontiguousarray(np.take(a, ok, axis=ax))
+    fleet = type(packed)(ok.size, packed.N, pick(packed.pdata, 1), pick(packed.n_obs, 0),
+                         pick(packed.xguess, 2), packed.duration)
+    srv = RtiServer(fleet, X=full["X"][ok], U=full["U"][ok])
+    oopts = _lib.default_opts()
+    oopts.rti = 1
+    d0 = None
+    for tick in range(3):
+        inp = srv.host_inputs()
+        ref = oracle.solve_packed(inp, opts=oopts)
+        srv.solve()
+        torch.cuda.synchronize()
+        gpu = {"X": srv.X.cpu().numpy(), "U": srv.U.cpu().numpy(), "status": srv.status.cpu().numpy(),
+               "sqp_iter": srv.sqp_iter.cpu().numpy(), "qp_iter": srv.qp_iter.cpu().numpy(),
+               "cost": srv.cost.cpu().numpy(), "res": srv.res.cpu().numpy()}
+        cases.assert_same_solution(gpu, ref, f"rti tick {tick}")
+        assert (gpu["sqp_iter"] == 1).all() and (gpu["status"] == 0).all()
+        u0 = srv.advance().cpu().numpy()
+        assert np.array_equal(u0, gpu["U"][:, 0, :])
+        x0 = srv.pdata[0:5].t().cpu().numpy()
+        d = np.hypot(x0[:, 0] - fleet.pdata[5], x0[:, 1] - fleet.pdata[6])
+        if d0 is not None:
+            assert d.mean() < d0.mean()
+        d0 = d

@@ -77,3 +77,41 @@ def test_solution_is_a_kkt_point(oracle):
         from mpc_amd import corridor_cal
         c1, a1, b1, c2, a2, b2 = corridor_cal(tuple(ego.state_start[:2]), tuple(ego.state_final[:2]), ego.corridor_width)
         assert (c1 * x[:, 1] + a1 * x[:, 0] + b1 > -tol).all() and (c2 * x[:, 1] + a2 * x[:, 0] + b2 < tol).all()
+
+
+def test_input_guess_warm_start(oracle):
+    """A converged solution handed back as state AND input guess passes the residual test
+    at once (0 QP solves); with the state guess alone (inputs zero, as the reference starts)
+    it does not."""
+    import copy
+    from mpc_amd.synthetic import synthetic_batch
+    packed = synthetic_batch(256)
+    ref = oracle.solve_packed(packed)
+    ok = np.nonzero(ref["status"] == 0)[0]
+    assert ok.size >= 10
+    sub = [packed.slice(int(b), int(b) + 1) for b in ok[:10]]
+    for b, p in zip(ok[:10], sub):
+        p.xguess = np.ascontiguousarray(np.transpose(ref["X"][b:b + 1], (1, 2, 0)))
+        cold = oracle.solve_packed(p)
+        p.uguess = np.ascontiguousarray(np.transpose(ref["U"][b:b + 1], (1, 2, 0)))
+        warm = oracle.solve_packed(p)
+        assert warm["status"][0] == 0 and warm["sqp_iter"][0] <= 1
+        assert cold["sqp_iter"][0] >= 1
+        assert np.allclose(warm["X"][0], ref["X"][b], atol=1e-3)
+
+
+def test_plant_step_matches_oracle_rk4(oracle):
+    from mpc_amd.rti import plant_step
+    import ctypes as C
+    lib = oracle.load()
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, (20, 5)); x[:, 4] *= 0.4
+    u = rng.uniform(-1, 1, (20, 2))
+    h = np.full(20, 0.1)
+    xn = plant_step(np, x, u, h, np.full(20, 2.7))
+    for i in range(20):
+        out = (C.c_double * 5)()
+        A = (C.c_double * 25)()
+        Bm = (C.c_double * 10)()
+        lib.mpcx_oracle_rk4(0.1, 2.7, (C.c_double * 5)(*x[i]), (C.c_double * 2)(*u[i]), out, A, Bm)
+        assert np.allclose(np.array(out[:]), xn[i], rtol=0, atol=1e-13)
