@@ -1,25 +1,31 @@
 // mpcx_kernels.hip — batched kinematic-car OCP solve on gfx950 (MI355X).
 //
-// Mapping.  One LANE per problem, 64 problems per wavefront, the whole SQP
-// solve fused in one persistent kernel.  The Riccati recursion is a serial
-// dependency chain over the N stages of ONE problem; a wavefront cooperating
-// on one 7x7 stage leaves most lanes idle and pays cross-lane latency on
-// every step, whereas 64 independent chains keep every FP64 instruction full.
-// The price is that a lane's working set (iterate, linearisation,
-// multipliers and Riccati factors of all N+1 stages, ~1.2 KB per stage) cannot
-// live on chip: it sits in an HBM workspace laid out [wave][stage][field][lane],
-// so each wavefront load/store is one contiguous 512-byte segment, and the
-// solver is organised as a few fused forward/backward SWEEPS over the stages
-// that touch each field as rarely as possible:
+// Mapping.  One persistent kernel, 64-lane workgroups, one wavefront per SIMD.  A
+// wavefront works in one of two modes, per tick:
 //
-//   L   forward : apply the SQP step, RK4 + sensitivities, NLP residuals,
-//                 cold start of the interior point (one per SQP iteration)
-//   B0  backward: apply the previous interior-point step, residuals, barrier
-//                 Hessian, Riccati factorisation + backward substitution
-//   F0  forward : affine step, its longest feasible length, centring sums
-//   B1  backward: corrector right-hand side + backward substitution
-//   F1  forward : corrector step and its length
-//   B2/F2       : centring-only re-solve when the corrector shortens the step
+//  * one LANE per problem (the bulk of a large batch).  The Riccati recursion is a
+//    serial chain over the N stages of ONE problem; 64 independent chains keep every
+//    FP64 instruction full.  The price is that a lane's working set (iterate,
+//    linearisation, multipliers and Riccati factors of all N+1 stages, ~1.2 KB per
+//    stage) cannot live on chip: it sits in an HBM workspace laid out
+//    [wave][stage][field][lane], so each wavefront load/store is one contiguous
+//    512-byte segment, and the solver is organised as a few fused forward/backward
+//    SWEEPS over the stages that touch each field as rarely as possible:
+//
+//      L   forward : apply the SQP step, RK4 + sensitivities, NLP residuals,
+//                    cold start of the interior point (one per SQP iteration)
+//      B0  backward: apply the previous interior-point step, residuals, barrier
+//                    Hessian, Riccati factorisation + backward substitution
+//      F   forward : affine step, its longest feasible length, centring sums
+//      Bs  backward: corrector AND centring-only right-hand sides, both substituted
+//      F   forward : both steps and their lengths (the centring-only one is taken
+//                    when the corrector would shorten the step)
+//
+//  * one lane per STAGE of a single problem (few problems left in the wavefront, small
+//    batches, long horizons): the rows of 64 stages are computed at once and the
+//    recursions run as a pipeline over the lanes; see "single-problem mode" below.
+//
+// Both modes perform the same operations in the same order for a problem.
 //
 // The problem is the one reference src/core_solver.py:127-351 poses and hands
 // to acados at :354/:502; the algorithm is the one its options block :242-253
@@ -1502,17 +1508,6 @@ DEV double uniform(double v)
     return __hiloint2double(hi, lo);
 }
 
-DEV AB bcast_ab(const AB &a, int k)
-{
-    AB r;
-    r.a02 = bcast(a.a02, k); r.a03 = bcast(a.a03, k); r.a04 = bcast(a.a04, k);
-    r.a12 = bcast(a.a12, k); r.a13 = bcast(a.a13, k); r.a14 = bcast(a.a14, k);
-    r.a23 = bcast(a.a23, k); r.a24 = bcast(a.a24, k);
-    r.b00 = bcast(a.b00, k); r.b10 = bcast(a.b10, k); r.b20 = bcast(a.b20, k);
-    r.b01 = bcast(a.b01, k); r.b11 = bcast(a.b11, k); r.b21 = bcast(a.b21, k);
-    return r;
-}
-
 // stores of one lane become visible to the loads of the others (same wavefront, same CU),
 // and loads issued so far have their data before any later store is issued
 DEV void coop_sync()
@@ -1938,7 +1933,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         const int n_qp = __popcll(__ballot(state == LS_QP));
         const bool few = n_qp <= coop_max;     // single-problem mode ahead
         if (n_wants >= svc_min || n_qp == 0 || (few && n_wants > 0)) {
-            const bool st_e = (state == LS_OUT);
+            [[maybe_unused]] const bool st_e = (state == LS_OUT);
             // the trajectory of each finished problem is copied out by the whole wavefront, a lane
             // per stage: one round trip to memory instead of one per stage
             const unsigned long long out_mask = __ballot(state == LS_OUT);
@@ -1975,7 +1970,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                 state = LS_FETCH;
             }
             STAMP(8, st_e);
-            const bool st_a = (state == LS_FETCH);
+            [[maybe_unused]] const bool st_a = (state == LS_FETCH);
             if (state == LS_FETCH) {
                 unsigned b = (unsigned)atomicAdd(counter, 1);
                 if (b >= B) {
@@ -2042,7 +2037,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             }
             if (new_mask != 0) coop_sync();
             STAMP(0, st_a);
-            const bool st_b = (state == LS_LIN);
+            [[maybe_unused]] const bool st_b = (state == LS_LIN);
             // few problems in the wavefront: sweep L of each with a lane per stage
             const unsigned long long lin_mask = __ballot(state == LS_LIN);
             const bool coop_lin = !o.rti && ((__popcll(lin_mask) + n_qp <= coop_max) || (__popcll(lin_mask) <= lin_max));
@@ -2170,7 +2165,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         }
 
         // ---- one interior-point iteration ---------------------------------------------------
-        const bool st_c = (state == LS_QP);
+        [[maybe_unused]] const bool st_c = (state == LS_QP);
         bool iterate = false;
         if (state == LS_QP) {
             sweep_B0<NH>(L, pc, op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, m_total, ret);
