@@ -147,7 +147,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "1M random start/goal pose OCPs, N=50, no obstacles, seed 20250310+rank",
+        "config": {"workload": f"{B} random start/goal pose OCPs per GPU, N=50, no obstacles, seed 20250310+rank",
                    "problems_per_gpu": B, "N": N, "problems_total": int(B_all),
                    "converged_fraction": n_conv_all / B_all,
                    "solved_per_sec_all_statuses": B_all * steps / elapsed,

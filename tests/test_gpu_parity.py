@@ -142,3 +142,50 @@ def test_rti_server_matches_oracle(oracle):
         if d0 is not None:
             assert d.mean() < d0.mean()
         d0 = d
+
+
+def test_edge_shapes_match_oracle(oracle, monkeypatch):
+    """Shortest horizon (N = 1), the maximum of four obstacles per problem, an empty batch,
+    and tight iteration limits (statuses 2 and QP iteration caps must agree too)."""
+    from mpc_amd.core_solver import EgoConfig, SimConfig
+    # N = 1
+    egos, sim = cases.obstacle_problems(40, 0.1)
+    packed = pack_problems(egos, sim)
+    assert packed.N == 1
+    for lanes in (1, 64):
+        monkeypatch.setenv("MPCX_LANES", str(lanes))
+        cases.assert_same_solution(_lib.solve_packed(packed), oracle.solve_packed(packed), f"N=1 lanes={lanes}")
+    # four obstacles
+    rng = np.random.default_rng(2)
+    egos = []
+    for b in range(48):
+        e = EgoConfig()
+        e.state_start = [0.0, 0.0, 0.0, 1.0, 0.0]
+        e.state_final = [12.0, rng.uniform(-1, 1), 0.0, 1.0, 0.0]
+        e.corridor_width = 6.0
+        e.obstacles = [[3.0 * (j + 1) - 1.0, (1 if (j + b) % 2 else -1) * rng.uniform(1.2, 3.0), 0.5, 0.3]
+                       for j in range(4)]
+        e.verbose = False
+        egos.append(e)
+    sim = SimConfig()
+    sim.duration = 8.0
+    packed = pack_problems(egos, sim)
+    assert packed.n_obs.max() == 4
+    ref = oracle.solve_packed(packed)
+    assert (ref["status"] == 0).sum() >= 10
+    for lanes in (2, 64):
+        monkeypatch.setenv("MPCX_LANES", str(lanes))
+        cases.assert_same_solution(_lib.solve_packed(packed), ref, f"4 obstacles lanes={lanes}")
+    monkeypatch.delenv("MPCX_LANES")
+    # tight limits
+    packed = synthetic_batch(500)
+    opts = _lib.default_opts()
+    opts.max_sqp_iter = 3
+    opts.max_qp_iter = 7
+    gpu = _lib.solve_packed(packed, opts=opts)
+    ref = oracle.solve_packed(packed, opts=opts)
+    cases.assert_same_solution(gpu, ref, "tight limits")
+    assert (ref["status"] == 2).any()
+    # empty batch
+    out = _lib.solve_packed(packed.slice(0, 0))
+    assert out["X"].shape == (0, packed.N + 1, 5) and out["status"].shape == (0,)
