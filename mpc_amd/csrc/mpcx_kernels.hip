@@ -1509,7 +1509,8 @@ DEV double uniform(double v)
 }
 
 // stores of one lane become visible to the loads of the others (same wavefront, same CU),
-// and loads issued so far have their data before any later store is issued
+// and loads issued so far have their data before any later store is issued.  Every
+// single-problem sweep begins with one; the caller places one after the last of them.
 DEV void coop_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1669,7 +1670,7 @@ DEV void coop_B0(const Lane &C, const PC<NH> &pc, const mpcx_opts *op, const Ste
     // blocks of 64 consecutive stages, the last block first
     for (int k0 = (N / 64) * 64; k0 >= 0; k0 -= 64)
         coop_B0_block<NH>(C, pc, op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, k0, ret);
-    coop_sync();
+    lds_order();
     const double ng = carry[CY_NORM + 0], nb = carry[CY_NORM + 1], nd = carry[CY_NORM + 2], nm = carry[CY_NORM + 3],
                  sum = carry[CY_NORM + 4];
     ret[0 * 64] = ng; ret[1 * 64] = nb; ret[2 * 64] = nd; ret[3 * 64] = nm;
@@ -1714,7 +1715,6 @@ __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_
         for (int i = 0; i < NX; ++i) { c1[i] = bcast(o1[i], 0); c2[i] = bcast(o2[i], 0); }
         if (kj <= N) store_rec<NH>(S, 0, kj < N, kj > 0, kvo, o1, o2);
     }
-    coop_sync();
 }
 
 template <int NH, int NS, bool ONE>
@@ -1789,7 +1789,6 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
             if (NS == 1) { s1 = s1 + bcast(a.s1, kk); s2 = s2 + bcast(a.s2, kk); }
         }
     }
-    coop_sync();
     if (NS == 1) { ret[0 * 64] = s1; ret[1 * 64] = s2; }
     else ret[0 * 64] = alpha[1];
     return alpha[0];
@@ -1840,7 +1839,6 @@ __device__ __attribute__((noinline)) void coop_L(Lane C, PC<NH> pc, const mpcx_o
             tot.cost = tot.cost + bcast(a.cost, kk);
         }
     }
-    coop_sync();
     ret[0 * 64] = tot.rs; ret[1 * 64] = tot.re; ret[2 * 64] = tot.ri; ret[3 * 64] = tot.rc;
     ret[4 * 64] = tot.cost;
 }
@@ -2054,6 +2052,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                                  r3 = uniform(ret[3 * 64]), r4 = uniform(ret[4 * 64]);
                     if ((int)threadIdx.x == p) { res[0] = r0; res[1] = r1; res[2] = r2; res[3] = r3; cost = r4; }
                 }
+                coop_sync();      // what the stage lanes stored is visible to the problems' own lanes
             }
             if (state == LS_LIN) {
                 if (o.rti && !first) {
@@ -2160,6 +2159,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                     sp = s;
                 }
             }
+            coop_sync();      // every single-problem sweep starts with one; this one is for the other mode
             STAMP(11, state != LS_DONE);
             continue;
         }
