@@ -970,11 +970,13 @@ DEV void stage_B0_peek(const Lane &L, int k, const Step &sp, double *vx, double 
 }
 
 // B0, Riccati part of stage k: factorisation and backward substitution of the affine
-// right-hand side; Pn, pn hold P(k+1), p(k+1) on entry and P(k), p(k) on return
+// right-hand side; Pn, pn = P(k+1), p(k+1); Po, po receive P(k), p(k) (may be the same arrays:
+// every read of the inputs precedes the first write of the outputs)
 struct RicOut { double prb[NX], l10, d0, d1, K[NU][NX], kv[NU]; };
 
 template <int KIND>
-DEV void stage_B0_ric(const Lane &L, const B0Out &in, double *Pn, double *pn, RicOut &ro)
+DEV void stage_B0_ric(const Lane &L, const B0Out &in, const double *Pn, const double *pn, double *Po, double *po,
+                      RicOut &ro)
 {
     if (KIND == LAST) {
         // P_N = barrier Hessian of the terminal state, p_N = its right-hand side
@@ -985,10 +987,10 @@ DEV void stage_B0_ric(const Lane &L, const B0Out &in, double *Pn, double *pn, Ri
                 double e = 0.0;
                 if (i == j) e = (i == 0) ? in.Ht[2] + in.hxx : (i == 1) ? in.Ht[3] + in.hyy : in.Ht[NU + i];
                 else if (i == 1 && j == 0) e = in.hxy;
-                Pn[tri(i, j)] = e;
+                Po[tri(i, j)] = e;
             }
 #pragma unroll
-        for (int i = 0; i < NX; ++i) pn[i] = in.gt[NU + i];
+        for (int i = 0; i < NX; ++i) po[i] = in.gt[NU + i];
     } else {
         // w = p(k+1) + P(k+1) rb
         double w[NX];
@@ -1065,14 +1067,14 @@ DEV void stage_B0_ric(const Lane &L, const B0Out &in, double *Pn, double *pn, Ri
             ro.kv[1] = -z1;
         }
 #pragma unroll
-        for (int i = 0; i < NX; ++i) pn[i] = fma(Kg[1][i], m[1], fma(Kg[0][i], m[0], m[NU + i]));
+        for (int i = 0; i < NX; ++i) po[i] = fma(Kg[1][i], m[1], fma(Kg[0][i], m[0], m[NU + i]));
         // P(k) = M_xx + M_xu K
 #pragma unroll
         for (int i = 0; i < NX; ++i)
 #pragma unroll
             for (int j = 0; j <= i; ++j) {
                 double e = fma(Mm[NU + i][0], Kg[0][j], Mm[NU + i][NU + j]);
-                Pn[tri(i, j)] = fma(Mm[NU + i][1], Kg[1][j], e);
+                Po[tri(i, j)] = fma(Mm[NU + i][1], Kg[1][j], e);
             }
     }
 }
@@ -1120,7 +1122,7 @@ __device__ __attribute__((noinline)) void sweep_B0(Lane L, PC<NH> pc, const mpcx
         B0Out t;                                                                       \
         stage_B0_rows<NH, KIND>(L, o, pc, kk, sp, vxn, qpin, t);                       \
         RicOut ro;                                                                     \
-        stage_B0_ric<KIND>(L, t, Pn, pn, ro);                                          \
+        stage_B0_ric<KIND>(L, t, Pn, pn, Pn, pn, ro);                                  \
         store_ric<NH>(L, kk, KIND != LAST, KIND != FIRST, ro, Pn);                     \
         ng = dmax(ng, t.ng); nb = dmax(nb, t.nb); nd = dmax(nd, t.nd); nm = dmax(nm, t.nm); \
         sum = sum + t.ssum;                                                            \
@@ -1633,7 +1635,7 @@ __device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const
     for (int i = 0; i < NX; ++i) po[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < 15; ++i) Po[i] = 0.0;
-    if (kj == N) stage_B0_ric<LAST>(S, t, Po, po, ro);
+    if (kj == N) stage_B0_ric<LAST>(S, t, Po, po, Po, po, ro);
     const int steps = (N - k0 < 64) ? N - k0 : 64;       // stages below N in this block
     for (int s = 0; s < steps; ++s) {
         double Pi[15], pi[NX];
@@ -1641,13 +1643,7 @@ __device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const
         for (int i = 0; i < 15; ++i) Pi[i] = from_lane_above(Po[i], cP[i]);
 #pragma unroll
         for (int i = 0; i < NX; ++i) pi[i] = from_lane_above(po[i], cp[i]);
-        if (kj < N) {
-            stage_B0_ric<MID>(S, t, Pi, pi, ro);
-#pragma unroll
-            for (int i = 0; i < 15; ++i) Po[i] = Pi[i];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) po[i] = pi[i];
-        }
+        if (kj < N) stage_B0_ric<MID>(S, t, Pi, pi, Po, po, ro);
     }
     if (j == 0) {
 #pragma unroll
