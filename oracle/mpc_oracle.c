@@ -39,7 +39,7 @@
  *
  * The file is valid C and valid C++: built as C++ with -DMPCX_COUNT_FLOPS the
  * scalar type counts operations (FMA = 2, + - * / = 1, sin and cos = 1 each),
- * which is how the flop constants quoted in DESIGN.md were frozen.
+ * which is how the flop constants of mpc_amd/flops.py were frozen.
  */
 #include <math.h>
 #include <stdint.h>

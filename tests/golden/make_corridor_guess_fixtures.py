@@ -3,7 +3,7 @@ guess rows computed by this repository's restatement (mpc_amd/corridor.py,
 mpc_amd/batch.py) for the cases the reference's own demo prints
 (utils/corridor.py:185-217) and for the two configurations whose guess takes
 different branches (path_finder: obstacle shift; default EgoConfig: none).
-The values were cross-checked by hand at i = 0, N/2, N (see DESIGN.md).
+The values were cross-checked by hand at i = 0, N/2, N.
 Run from the repository root:  python tests/golden/make_corridor_guess_fixtures.py
 """
 import json
