@@ -39,6 +39,7 @@
 // a CPU program that performs the dense sequence gets the same bits.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "../../include/mpcx.h"
@@ -1511,8 +1512,11 @@ DEV double uniform(double v)
 }
 
 // stores of one lane become visible to the loads of the others (same wavefront, same CU),
-// and loads issued so far have their data before any later store is issued.  Every
-// single-problem sweep begins with one; the caller places one after the last of them.
+// and loads issued so far have their data before any later store is issued.  The sweeps of
+// one interior-point iteration need none between them: in all of them a lane loads and stores
+// fields of its own stage only (the lanes talk through DPP moves), and a thread sees its own
+// stores.  One is needed where the mapping of lanes to data changes: before the first of the
+// sweeps, inside sweep L (which reads the next stage), and when going back to one lane per problem.
 DEV void coop_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1660,7 +1664,6 @@ DEV void coop_B0(const Lane &C, const PC<NH> &pc, const mpcx_opts *op, const Ste
 {
     const int N = C.N;
     ldouble *carry = ret - threadIdx.x + 5 * 64;
-    coop_sync();
     if (threadIdx.x < CY_N) carry[threadIdx.x] = 0.0;
     lds_order();
     // blocks of 64 consecutive stages, the last block first
@@ -1679,7 +1682,6 @@ __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_
     const mpcx_opts &o = *op;
     const int N = C.N;
     const int j = (int)threadIdx.x;
-    coop_sync();
     double c1[NX], c2[NX];          // p of the lowest stage of the block above, both systems
 #pragma unroll
     for (int i = 0; i < NX; ++i) { c1[i] = 0.0; c2[i] = 0.0; }
@@ -1720,7 +1722,6 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
     const mpcx_opts &o = *op;
     const int N = C.N;
     const int j = (int)threadIdx.x;
-    coop_sync();
     double cdx[NS][NX];          // state step that enters the first stage of the block
 #pragma unroll
     for (int q = 0; q < NS; ++q)
@@ -1853,7 +1854,8 @@ __device__ __attribute__((noinline)) void coop_L(Lane C, PC<NH> pc, const mpcx_o
 #ifdef MPCX_STAMPS
 #define N_STAMP 32
 __device__ unsigned long long g_stamps[2048][N_STAMP];
-#define STAMP_BEGIN() unsigned long long st_t0 = __builtin_amdgcn_s_memtime()
+#define STAMP_DECL() unsigned long long st_t0 = 0
+#define STAMP_BEGIN() st_t0 = __builtin_amdgcn_s_memtime()
 #define STAMP(slot, pred)                                                              \
     do {                                                                               \
         unsigned long long st_t1 = __builtin_amdgcn_s_memtime();                       \
@@ -1865,6 +1867,7 @@ __device__ unsigned long long g_stamps[2048][N_STAMP];
         st_t0 = __builtin_amdgcn_s_memtime();                                          \
     } while (0)
 #else
+#define STAMP_DECL() ((void)0)
 #define STAMP_BEGIN() ((void)0)
 #define STAMP(slot, pred) ((void)0)
 #endif
@@ -1886,7 +1889,8 @@ enum LaneState {
 // time in single-problem mode.)
 template <int NH>
 __global__ void __launch_bounds__(64)
-mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min)
+mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
+                int boost_min, int boost_div, int boost_cap)
 {
     const mpcx_opts &o = *op;
     typedef Map<NH> M;
@@ -1918,6 +1922,106 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     double cost = 0.0;
     Step sp;
     sp.have = false; sp.mode = 0; sp.sigma_mu = 0.0; sp.alpha = 0.0;
+
+    STAMP_DECL();
+    // what a lane decides after sweep L of its problem (not in real-time-iteration mode's second call)
+    auto after_L = [&]() {
+        first = false;
+        state = LS_OUT;
+        if (!(finite_d(res[0]) && finite_d(res[1]) && finite_d(res[2]) && finite_d(res[3]))) {
+            status = MPCX_NAN;
+        } else if (!o.rti && res[0] < o.tol_stat && res[1] < o.tol_eq && res[2] < o.tol_ineq &&
+                   res[3] < o.tol_comp) {
+            status = MPCX_SUCCESS;
+        } else if (sqp_it >= o.max_sqp_iter) {
+            status = MPCX_MAXITER;
+        } else {
+            state = LS_QP;
+            sp.have = false;
+            qp_it = 0;
+        }
+    };
+    // sweep L of the problem of lane p, the wavefront with a lane per stage; results into lane p
+    auto single_L = [&](int p) {
+        Lane C;
+        PC<NH> pcc;
+        problem_of_lane<NH>(L, pc, (ldouble *)pc_lds, p, C, pcc);
+        const bool fp = __builtin_amdgcn_readlane((int)first, p) != 0;
+        if (N < 64) coop_L<NH, true>(C, pcc, op, fp, ret);
+        else coop_L<NH, false>(C, pcc, op, fp, ret);
+        const double r0 = uniform(ret[0 * 64]), r1 = uniform(ret[1 * 64]), r2 = uniform(ret[2 * 64]),
+                     r3 = uniform(ret[3 * 64]), r4 = uniform(ret[4 * 64]);
+        if ((int)threadIdx.x == p) { res[0] = r0; res[1] = r1; res[2] = r2; res[3] = r3; cost = r4; }
+    };
+    // one interior-point iteration of the problem of lane p, the wavefront with a lane per stage
+    auto single_qp = [&](int p) {
+        coop_sync();
+        Lane C;
+        PC<NH> pcc;
+        problem_of_lane<NH>(L, pc, (ldouble *)pc_lds, p, C, pcc);
+        Step s;
+        s.have = __builtin_amdgcn_readlane((int)sp.have, p) != 0;
+        s.mode = __builtin_amdgcn_readlane(sp.mode, p);
+        s.sigma_mu = bcast(sp.sigma_mu, p);
+        s.alpha = bcast(sp.alpha, p);
+        const int mt = __builtin_amdgcn_readlane(m_total, p);
+        int qit = __builtin_amdgcn_readlane(qp_it, p);
+        int n_state = LS_QP, n_status = -1, add_total = 0, add_sqp = 0;
+        coop_B0<NH>(C, pcc, op, s, mt, ret);
+        STAMP(12, true);
+        const double Rg = uniform(ret[0 * 64]), Rb = uniform(ret[1 * 64]), Rd = uniform(ret[2 * 64]),
+                     Rm = uniform(ret[3 * 64]), mu = uniform(ret[4 * 64]);
+        int qs = -1;
+        if (!(finite_d(Rg) && finite_d(Rb) && finite_d(Rd) && finite_d(Rm))) qs = 3;
+        else if (Rg < o.qp_tol_stat && Rb < o.qp_tol_eq && Rd < o.qp_tol_ineq && Rm < o.qp_tol_comp) qs = 0;
+        else if (qit >= o.max_qp_iter) qs = 1;
+        if (qs >= 0) {
+            add_total = qit;
+            add_sqp = 1;
+            if (qs == 3) { n_status = MPCX_QP_FAILURE; n_state = LS_OUT; }
+            else n_state = LS_LIN;
+        } else {
+            const double a_aff = uniform((N < 64) ? coop_F<NH, 1, true>(C, pcc, op, 0.0, ret)
+                                                  : coop_F<NH, 1, false>(C, pcc, op, 0.0, ret));
+            STAMP(13, true);
+            const double S1 = uniform(ret[0 * 64]), S2 = uniform(ret[1 * 64]);
+            double S0 = mu * (double)mt;
+            double mu_aff = fma(a_aff, fma(a_aff, S2, S1), S0) / (double)mt;
+            if (mu_aff < 0.0) mu_aff = 0.0;
+            double ratio = mu_aff / mu;
+            double sigma = ratio * ratio * ratio;
+            const double sigma_mu = sigma * mu;
+            if (N < 64) coop_Bs<NH, true>(C, pcc, op, sigma_mu);
+            else coop_Bs<NH, false>(C, pcc, op, sigma_mu);
+            STAMP(14, true);
+            const double alpha1 = uniform((N < 64) ? coop_F<NH, 2, true>(C, pcc, op, sigma_mu, ret)
+                                                   : coop_F<NH, 2, false>(C, pcc, op, sigma_mu, ret));
+            const double alpha2 = uniform(ret[0 * 64]);
+            STAMP(15, true);
+            const bool use2 = o.cond_pred_corr && (alpha1 < a_aff);
+            const double alpha = use2 ? alpha2 : alpha1;
+            ++qit;
+            if (!(alpha > o.alpha_min)) {
+                add_total = qit;
+                add_sqp = 1;
+                n_status = MPCX_QP_FAILURE;
+                n_state = LS_OUT;
+            } else {
+                s.have = true;
+                s.mode = use2 ? 2 : 1;
+                s.sigma_mu = sigma_mu;
+                s.alpha = alpha * fma(alpha, 0.9999999, (1.0 - alpha) * 0.99);
+            }
+        }
+        if ((int)threadIdx.x == p) {
+            state = n_state;
+            if (n_status >= 0) status = n_status;
+            qp_total += add_total;
+            sqp_it += add_sqp;
+            qp_it = qit;
+            sp = s;
+        }
+    };
 
     for (;;) {
         STAMP_BEGIN();
@@ -2036,18 +2140,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             const unsigned long long lin_mask = __ballot(state == LS_LIN);
             const bool coop_lin = !o.rti && ((__popcll(lin_mask) + n_qp <= coop_max) || (__popcll(lin_mask) <= lin_max));
             if (coop_lin) {
-                for (unsigned long long rest = lin_mask; rest != 0; rest &= rest - 1) {
-                    const int p = __ffsll((long long)rest) - 1;
-                    Lane C;
-                    PC<NH> pcc;
-                    problem_of_lane<NH>(L, pc, (ldouble *)pc_lds, p, C, pcc);
-                    const bool fp = __builtin_amdgcn_readlane((int)first, p) != 0;
-                    if (N < 64) coop_L<NH, true>(C, pcc, op, fp, ret);
-                    else coop_L<NH, false>(C, pcc, op, fp, ret);
-                    const double r0 = uniform(ret[0 * 64]), r1 = uniform(ret[1 * 64]), r2 = uniform(ret[2 * 64]),
-                                 r3 = uniform(ret[3 * 64]), r4 = uniform(ret[4 * 64]);
-                    if ((int)threadIdx.x == p) { res[0] = r0; res[1] = r1; res[2] = r2; res[3] = r3; cost = r4; }
-                }
+                for (unsigned long long rest = lin_mask; rest != 0; rest &= rest - 1) single_L(__ffsll((long long)rest) - 1);
                 coop_sync();      // what the stage lanes stored is visible to the problems' own lanes
             }
             if (state == LS_LIN) {
@@ -2064,20 +2157,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                         for (int i = 0; i < 4; ++i) res[i] = ret[i * 64];
                         cost = ret[4 * 64];
                     }
-                    first = false;
-                    state = LS_OUT;
-                    if (!(finite_d(res[0]) && finite_d(res[1]) && finite_d(res[2]) && finite_d(res[3]))) {
-                        status = MPCX_NAN;
-                    } else if (!o.rti && res[0] < o.tol_stat && res[1] < o.tol_eq && res[2] < o.tol_ineq &&
-                               res[3] < o.tol_comp) {
-                        status = MPCX_SUCCESS;
-                    } else if (sqp_it >= o.max_sqp_iter) {
-                        status = MPCX_MAXITER;
-                    } else {
-                        state = LS_QP;
-                        sp.have = false;
-                        qp_it = 0;
-                    }
+                    after_L();
                 }
             }
             STAMP(1, st_b);
@@ -2087,74 +2167,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         // ---- few problems left: one interior-point iteration of each, the wavefront on one problem
         const unsigned long long qp_mask = __ballot(state == LS_QP);
         if (__popcll(qp_mask) <= coop_max) {
-            for (unsigned long long rest = qp_mask; rest != 0; rest &= rest - 1) {
-                const int p = __ffsll((long long)rest) - 1;
-                Lane C;
-                PC<NH> pcc;
-                problem_of_lane<NH>(L, pc, (ldouble *)pc_lds, p, C, pcc);
-                Step s;
-                s.have = __builtin_amdgcn_readlane((int)sp.have, p) != 0;
-                s.mode = __builtin_amdgcn_readlane(sp.mode, p);
-                s.sigma_mu = bcast(sp.sigma_mu, p);
-                s.alpha = bcast(sp.alpha, p);
-                const int mt = __builtin_amdgcn_readlane(m_total, p);
-                int qit = __builtin_amdgcn_readlane(qp_it, p);
-                int n_state = LS_QP, n_status = -1, add_total = 0, add_sqp = 0;
-                coop_B0<NH>(C, pcc, op, s, mt, ret);
-                STAMP(12, true);
-                const double Rg = uniform(ret[0 * 64]), Rb = uniform(ret[1 * 64]), Rd = uniform(ret[2 * 64]),
-                             Rm = uniform(ret[3 * 64]), mu = uniform(ret[4 * 64]);
-                int qs = -1;
-                if (!(finite_d(Rg) && finite_d(Rb) && finite_d(Rd) && finite_d(Rm))) qs = 3;
-                else if (Rg < o.qp_tol_stat && Rb < o.qp_tol_eq && Rd < o.qp_tol_ineq && Rm < o.qp_tol_comp) qs = 0;
-                else if (qit >= o.max_qp_iter) qs = 1;
-                if (qs >= 0) {
-                    add_total = qit;
-                    add_sqp = 1;
-                    if (qs == 3) { n_status = MPCX_QP_FAILURE; n_state = LS_OUT; }
-                    else n_state = LS_LIN;
-                } else {
-                    const double a_aff = uniform((N < 64) ? coop_F<NH, 1, true>(C, pcc, op, 0.0, ret)
-                                                          : coop_F<NH, 1, false>(C, pcc, op, 0.0, ret));
-                    STAMP(13, true);
-                    const double S1 = uniform(ret[0 * 64]), S2 = uniform(ret[1 * 64]);
-                    double S0 = mu * (double)mt;
-                    double mu_aff = fma(a_aff, fma(a_aff, S2, S1), S0) / (double)mt;
-                    if (mu_aff < 0.0) mu_aff = 0.0;
-                    double ratio = mu_aff / mu;
-                    double sigma = ratio * ratio * ratio;
-                    const double sigma_mu = sigma * mu;
-                    if (N < 64) coop_Bs<NH, true>(C, pcc, op, sigma_mu);
-                    else coop_Bs<NH, false>(C, pcc, op, sigma_mu);
-                    STAMP(14, true);
-                    const double alpha1 = uniform((N < 64) ? coop_F<NH, 2, true>(C, pcc, op, sigma_mu, ret)
-                                                           : coop_F<NH, 2, false>(C, pcc, op, sigma_mu, ret));
-                    const double alpha2 = uniform(ret[0 * 64]);
-                    STAMP(15, true);
-                    const bool use2 = o.cond_pred_corr && (alpha1 < a_aff);
-                    const double alpha = use2 ? alpha2 : alpha1;
-                    ++qit;
-                    if (!(alpha > o.alpha_min)) {
-                        add_total = qit;
-                        add_sqp = 1;
-                        n_status = MPCX_QP_FAILURE;
-                        n_state = LS_OUT;
-                    } else {
-                        s.have = true;
-                        s.mode = use2 ? 2 : 1;
-                        s.sigma_mu = sigma_mu;
-                        s.alpha = alpha * fma(alpha, 0.9999999, (1.0 - alpha) * 0.99);
-                    }
-                }
-                if ((int)threadIdx.x == p) {
-                    state = n_state;
-                    if (n_status >= 0) status = n_status;
-                    qp_total += add_total;
-                    sqp_it += add_sqp;
-                    qp_it = qit;
-                    sp = s;
-                }
-            }
+            for (unsigned long long rest = qp_mask; rest != 0; rest &= rest - 1) single_qp(__ffsll((long long)rest) - 1);
             coop_sync();      // every single-problem sweep starts with one; this one is for the other mode
             STAMP(11, state != LS_DONE);
             continue;
@@ -2215,6 +2228,43 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             }
         }
         STAMP(5, iterate);
+        // ---- old problems get extra iterations, the wavefront on one problem at a time -------
+        // A problem that has already taken many iterations is likely to take many more, and the
+        // longest problem of a batch bounds its run time, so the extra iterations grow with the
+        // age: age / boost_div per tick of the wavefront, oldest first, boost_cap in total.
+        // They cost no HBM traffic (one problem's working set stays in L2), which is what the
+        // other wavefronts are waiting for.
+        if (boost_div > 0 && !o.rti) {
+            int budget = boost_cap;
+            unsigned long long seen = 0;
+            for (;;) {
+                const int age = qp_total + ((state == LS_QP) ? qp_it : 0);
+                const bool cand = ((state == LS_QP) || (state == LS_LIN)) && age >= boost_min &&
+                                  !((seen >> threadIdx.x) & 1ull);
+                const unsigned long long cm = __ballot(cand);
+                if (cm == 0 || budget <= 0) break;
+                int p = -1, best = -1;
+                for (unsigned long long rest = cm; rest != 0; rest &= rest - 1) {
+                    const int i = __ffsll((long long)rest) - 1;
+                    const int a = __builtin_amdgcn_readlane(age, i);
+                    if (a > best) { best = a; p = i; }
+                }
+                seen |= 1ull << p;
+                int k = best / boost_div;
+                if (k > budget) k = budget;
+                budget -= k;
+                for (int t = 0; t < k; ++t) {
+                    const int st = __builtin_amdgcn_readlane(state, p);
+                    if (st == LS_QP) single_qp(p);
+                    else if (st == LS_LIN) {
+                        single_L(p);
+                        if ((int)threadIdx.x == p) after_L();
+                    } else break;
+                }
+            }
+            if (seen != 0) coop_sync();
+            STAMP(11, seen != 0);
+        }
         STAMP(9, state != LS_DONE);      // lanes-sum / 64 = ticks; lanes that still have work
         STAMP(10, true);
     }
@@ -2246,6 +2296,11 @@ size_t mpcx_stage_doubles(int nh)
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
                            double *workspace, int n_waves, int lanes, int coop_max, int lin_max, hipStream_t stream)
 {
+    int boost_min = 100, boost_div = 2, boost_cap = 4096;
+    if (const char *e = getenv("MPCX_BOOST")) {      // "min,div,cap"; div 0 switches the extra iterations off
+        int a = 0, b = 0, c = 0;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a >= 0 && b >= 0 && c >= 0) { boost_min = a; boost_div = b; boost_cap = c; }
+    }
     int svc_min = MPCX_SERVICE_MIN;
     if (const char *e = getenv("MPCX_SVC_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) svc_min = v; }
     if (coop_max < 0 || coop_max > 64) return hipErrorInvalidValue;
@@ -2262,12 +2317,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     if (e != hipSuccess) return e;
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap); break;
 #else
     default: return hipErrorInvalidValue;
 #endif

@@ -31,7 +31,7 @@ buf = np.zeros((2048, NS), dtype=np.uint64)
 lib.mpcx_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.mpcx_debug_read_stamps(buf.ctypes.data, 1) == 0
 names = ["A fetch+init", "B sweep L", "sweep B0", "sweep F (affine)", "sweep Bs (both rhs)", "sweep F (both steps)",
-         "-", "-", "E write-out", "busy lanes", "ticks*64", "single-problem ticks", "  single B0", "  single F (affine)",
+         "-", "-", "E write-out", "busy lanes", "ticks*64", "single-problem ticks / extra iterations", "  single B0", "  single F (affine)",
          "  single Bs", "  single F (both)"]
 cyc = buf[:, 0::2].astype(np.float64)
 cnt = buf[:, 1::2].astype(np.float64)
