@@ -766,20 +766,27 @@ struct B0Out {
     double ng, nb, nd, nm, ssum;
 };
 
-// B0, row part of stage k: applies the pending step to the stage's iterate, then residuals,
-// barrier Hessian and affine right-hand side.  vxn / qpin: updated x-part of v and dynamics
-// multiplier of stage k+1.
+// everything B0 reads of a stage, and the stage's primal iterate after the pending step
+template <int NH>
+struct B0In {
+    double x[NX], u[NU], v[NZ], vo[NZ], dv[NZ], dva[NZ], qpi[NX];
+    double ll[Map<NH>::R], lu[Map<NH>::R], tl[Map<NH>::R], tu[Map<NH>::R], til_[Map<NH>::R], tiu_[Map<NH>::R];
+    AB ab;
+    double bv[NX];
+};
+
+// first half: all loads of the stage, then the pending step on v and on the dynamics multiplier
 template <int NH, int KIND>
-DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, const Step &sp,
-                       const double *vxn, const double *qpin, B0Out &out, const KR &kr = KR{false, false})
+DEV void stage_B0_head(const Lane &L, int k, const Step &sp, B0In<NH> &in, const KR &kr = KR{false, false})
 {
-    out.ng = out.nb = out.nd = out.nm = 0.0;
     typedef Map<NH> M;
     // ---- loads ----
     const int sol = (sp.mode == 2) ? M::SOL2 : 0;      // which of the two stored solutions is the step
-    double ssum = 0.0;
-    double x[NX], u[NU], v[NZ], vo[NZ], dv[NZ], dva[NZ], qpi[NX], dpi[NX];
-    double ll[M::R], lu[M::R], tl[M::R], tu[M::R], til_[M::R], tiu_[M::R];
+    double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&vo)[NZ] = in.vo, (&dv)[NZ] = in.dv,
+           (&dva)[NZ] = in.dva, (&qpi)[NX] = in.qpi;
+    double dpi[NX];
+    double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
+           (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
     load_xu<NH, KIND>(L, k, kr, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
@@ -805,8 +812,11 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
             tiu_[r] = ldw(L, k, M::TIU + r);
         }
     }
-    AB ab = {};
-    double bv[NX];
+    AB &ab = in.ab;
+    double (&bv)[NX] = in.bv;
+    ab = AB{};
+#pragma unroll
+    for (int i = 0; i < NX; ++i) bv[i] = 0.0;
     if (KIND != LAST) {
         load_ab<NH>(L, k, ab);
 #pragma unroll
@@ -830,6 +840,23 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
             stw(L, k, M::QPI + i, qpi[i]);
         }
     }
+}
+
+// second half: rows, residuals, barrier Hessian, affine right-hand side.  vxn / qpin: updated
+// x-part of v and dynamics multiplier of stage k+1.
+template <int NH, int KIND>
+DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, const Step &sp, B0In<NH> &in,
+                       const double *vxn, const double *qpin, B0Out &out, const KR &kr = KR{false, false})
+{
+    typedef Map<NH> M;
+    out.ng = out.nb = out.nd = out.nm = 0.0;
+    double ssum = 0.0;
+    double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&vo)[NZ] = in.vo, (&dv)[NZ] = in.dv,
+           (&dva)[NZ] = in.dva, (&qpi)[NX] = in.qpi;
+    double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
+           (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
+    AB &ab = in.ab;
+    double (&bv)[NX] = in.bv;
     double g[NZ], Ht[NZ], rg[NZ], hxx = 0.0, hxy = 0.0, hyy = 0.0;
     cost_terms<NH, KIND>(L, o, pc, kr, x, u, g, Ht);
 #pragma unroll
@@ -954,20 +981,15 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
     }
 }
 
-// updated x-part of v and dynamics multiplier of stage k (what stage_B0_rows of stage k
-// computes for them), for a lane that works on stage k-1 without having processed stage k
-template <int NH>
-DEV void stage_B0_peek(const Lane &L, int k, const Step &sp, double *vx, double *qpi)
+// B0, row part of stage k: applies the pending step to the stage's iterate, then residuals,
+// barrier Hessian and affine right-hand side
+template <int NH, int KIND>
+DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, const Step &sp,
+                       const double *vxn, const double *qpin, B0Out &out)
 {
-    typedef Map<NH> M;
-    const int sol = (sp.mode == 2) ? M::SOL2 : 0;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        const double v0 = ldw(L, k, M::V + NU + i), d = ldw_lane(L, k, M::DV + NU + i, sol);
-        const double q0 = ldw(L, k, M::QPI + i), dq = ldw_lane(L, k, M::DPI + i, sol);
-        vx[i] = sp.have ? fma(sp.alpha, d, v0) : v0;
-        qpi[i] = sp.have ? fma(sp.alpha, dq, q0) : q0;
-    }
+    B0In<NH> in;
+    stage_B0_head<NH, KIND>(L, k, sp, in);
+    stage_B0_tail<NH, KIND>(L, o, pc, k, sp, in, vxn, qpin, out);
 }
 
 // B0, Riccati part of stage k: factorisation and backward substitution of the affine
@@ -1325,13 +1347,22 @@ DEV void F_rec(const Lane &L, const AB &ab, const double (*kg)[NX], const double
     mul_AB(L, ab, dx, du, rb, dxn);
 }
 
+// everything a forward sweep reads of a stage
+template <int NH, int NS>
+struct FIn {
+    double x[NX], u[NU], v[NZ], dva[NZ];
+    double ll[Map<NH>::R], lu[Map<NH>::R], tl[Map<NH>::R], tu[Map<NH>::R], til_[Map<NH>::R], tiu_[Map<NH>::R];
+    AB ab;
+    double rb[NX], kv[NS][NU], kg[NU][NX], pv[NS][NX], Pk[15];
+};
+
 template <int NH, int KIND, int NS>
-DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu,
-                 double (*dx)[NX], FAcc &a, const KR &kr = KR{false, false})
+DEV void stage_F_load(const Lane &L, int k, FIn<NH, NS> &in, const KR &kr = KR{false, false})
 {
     typedef Map<NH> M;
-    double x[NX], u[NU], v[NZ], dva[NZ], dvk[NS][NZ], dxn[NS][NX];
-    double ll[M::R], lu[M::R], tl[M::R], tu[M::R], til_[M::R], tiu_[M::R];
+    double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&dva)[NZ] = in.dva;
+    double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
+           (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
     load_xu<NH, KIND>(L, k, kr, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
@@ -1351,8 +1382,13 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, dou
             tiu_[r] = ldw(L, k, M::TIU + r);
         }
     }
-    AB ab = {};
-    double rb[NX], kv[NS][NU], kg[NU][NX], pv[NS][NX], Pk[15];
+    AB &ab = in.ab;
+    double (&rb)[NX] = in.rb, (&kv)[NS][NU] = in.kv, (&kg)[NU][NX] = in.kg, (&pv)[NS][NX] = in.pv, (&Pk)[15] = in.Pk;
+    ab = AB{};
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { rb[i] = 0.0; kg[0][i] = 0.0; kg[1][i] = 0.0; }
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { kv[q][0] = 0.0; kv[q][1] = 0.0; }
     if (KIND != LAST) {
         load_ab<NH>(L, k, ab);
 #pragma unroll
@@ -1376,6 +1412,19 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, dou
         for (int i = 0; i < 15; ++i) Pk[i] = ldw(L, k, M::P + i);
     }
     __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NH, int KIND, int NS>
+DEV void stage_F_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu,
+                         FIn<NH, NS> &in, double (*dx)[NX], FAcc &a, const KR &kr = KR{false, false})
+{
+    typedef Map<NH> M;
+    double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&dva)[NZ] = in.dva;
+    double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
+           (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
+    AB &ab = in.ab;
+    double (&rb)[NX] = in.rb, (&kv)[NS][NU] = in.kv, (&kg)[NU][NX] = in.kg, (&pv)[NS][NX] = in.pv, (&Pk)[15] = in.Pk;
+    double dvk[NS][NZ], dxn[NS][NX];
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
 #pragma unroll
@@ -1464,6 +1513,15 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, dou
     for (int q = 0; q < NS; ++q)
 #pragma unroll
         for (int i = 0; i < NX; ++i) dx[q][i] = dxn[q][i];
+}
+
+template <int NH, int KIND, int NS>
+DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu,
+                 double (*dx)[NX], FAcc &a)
+{
+    FIn<NH, NS> in;
+    stage_F_load<NH, KIND, NS>(L, k, in);
+    stage_F_compute<NH, KIND, NS>(L, o, pc, k, sigma_mu, in, dx, a);
 }
 
 // NS = 1: returns the affine step length, ret[0], ret[1] = S1, S2.
@@ -1594,24 +1652,23 @@ __device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const
     const Lane S = stage_lane(C, (unsigned)kj);
     // the stage above supplies its updated state and multiplier: the lane above, or the
     // lowest stage of the block above
-    double vx[NX], qpi[NX], vxn[NX], qpin[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { vx[i] = 0.0; qpi[i] = 0.0; }
-    if (kj <= N) stage_B0_peek<NH>(S, 0, sp, vx, qpi);
+    const KR kr = {kj == 0, kj == N};
+    B0In<NH> ld = {};
+    if (kj <= N) stage_B0_head<NH, ANY>(S, 0, sp, ld, kr);
+    double vxn[NX], qpin[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        vxn[i] = from_lane_above(vx[i], carry[CY_VX + i]);
-        qpin[i] = from_lane_above(qpi[i], carry[CY_QPI + i]);
+        vxn[i] = from_lane_above(ld.v[NU + i], carry[CY_VX + i]);
+        qpin[i] = from_lane_above(ld.qpi[i], carry[CY_QPI + i]);
     }
     lds_order();
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        const double a = bcast(vx[i], 0), b = bcast(qpi[i], 0);
+        const double a = bcast(ld.v[NU + i], 0), b = bcast(ld.qpi[i], 0);
         if (j == 0) { carry[CY_VX + i] = a; carry[CY_QPI + i] = b; }
     }
     B0Out t = {};
-    const KR kr = {kj == 0, kj == N};
-    if (kj <= N) stage_B0_rows<NH, ANY>(S, o, pc, 0, sp, vxn, qpin, t, kr);
+    if (kj <= N) stage_B0_tail<NH, ANY>(S, o, pc, 0, sp, ld, vxn, qpin, t, kr);
     // reductions over the stages of the block, downwards
     const int kend = (N - k0 < 63) ? N - k0 : 63;
     lds_order();
@@ -1717,7 +1774,6 @@ __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_
 
 template <int NH, int NS, bool ONE>
 __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx_opts *op, double sigma_mu, ldouble *ret)
-{
     typedef Map<NH> M;
     const mpcx_opts &o = *op;
     const int N = C.N;
@@ -1731,27 +1787,10 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
     for (int k0 = 0; ONE ? (k0 == 0) : (k0 <= N); k0 += 64) {
         const int kj = k0 + j;
         const Lane S = stage_lane(C, (unsigned)kj);
-        // what the recursion needs of this lane's stage
-        AB ab = {};
-        double rb[NX], kg[NU][NX], kv[NS][NU];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { rb[i] = 0.0; kg[0][i] = 0.0; kg[1][i] = 0.0; }
-#pragma unroll
-        for (int q = 0; q < NS; ++q) { kv[q][0] = 0.0; kv[q][1] = 0.0; }
-        if (kj < N) {
-            load_ab<NH>(S, 0, ab);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                rb[i] = ldw(S, 0, M::RB + i);
-                kg[0][i] = ldw(S, 0, M::K + i);
-                kg[1][i] = ldw(S, 0, M::K + NX + i);
-            }
-#pragma unroll
-            for (int q = 0; q < NS; ++q) {
-                kv[q][0] = ldw(S, 0, M::KV + q * M::SOL2 + 0);
-                kv[q][1] = ldw(S, 0, M::KV + q * M::SOL2 + 1);
-            }
-        }
+        // everything the sweep reads of this lane's stage, in one round trip
+        const KR kr = {kj == 0, kj == N};
+        FIn<NH, NS> ld = {};
+        if (kj <= N) stage_F_load<NH, ANY, NS>(S, 0, ld, kr);
         // the recursion up the lanes: dxi = state step entering this lane's stage, dxo = leaving it
         const int kend = (N - k0 < 63) ? N - k0 : 63;
         double dxi[NS][NX], dxo[NS][NX];
@@ -1766,7 +1805,7 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
                 for (int i = 0; i < NX; ++i) dxi[q][i] = from_lane_below(dxo[q][i], cdx[q][i]);
                 if (kj < N) {
                     double du[NU];
-                    F_rec(C, ab, kg, kv[q], rb, dxi[q], du, dxo[q]);
+                    F_rec(C, ld.ab, ld.kg, ld.kv[q], ld.rb, dxi[q], du, dxo[q]);
                 }
             }
         }
@@ -1775,8 +1814,7 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
 #pragma unroll
             for (int i = 0; i < NX; ++i) cdx[q][i] = bcast(dxo[q][i], 63);
         FAcc a = {{1.0, 1.0}, 0.0, 0.0};
-        const KR kr = {kj == 0, kj == N};
-        if (kj <= N) stage_F<NH, ANY, NS>(S, o, pc, 0, sigma_mu, dxi, a, kr);
+        if (kj <= N) stage_F_compute<NH, ANY, NS>(S, o, pc, 0, sigma_mu, ld, dxi, a, kr);
         for (int kk = 0; kk <= kend; ++kk) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
@@ -1852,7 +1890,7 @@ __device__ __attribute__((noinline)) void coop_L(Lane C, PC<NH> pc, const mpcx_o
 // of the tick loop, read back by mpcx_debug_read_stamps().  No stamp code is
 // compiled into the shipped library.
 #ifdef MPCX_STAMPS
-#define N_STAMP 32
+#define N_STAMP 48
 __device__ unsigned long long g_stamps[2048][N_STAMP];
 #define STAMP_DECL() unsigned long long st_t0 = 0
 #define STAMP_BEGIN() st_t0 = __builtin_amdgcn_s_memtime()
@@ -1866,7 +1904,15 @@ __device__ unsigned long long g_stamps[2048][N_STAMP];
         }                                                                              \
         st_t0 = __builtin_amdgcn_s_memtime();                                          \
     } while (0)
+// wall-clock marks (100 MHz counter): the slot keeps the time of the first call
+#define MARK(slot)                                                                     \
+    do {                                                                               \
+        if (g_stamps[blockIdx.x][2 * (slot)] == 0) g_stamps[blockIdx.x][2 * (slot)] = wall_clock64(); \
+    } while (0)
+#define MARK_LAST(slot) do { g_stamps[blockIdx.x][2 * (slot)] = wall_clock64(); } while (0)
 #else
+#define MARK(slot) ((void)0)
+#define MARK_LAST(slot) ((void)0)
 #define STAMP_DECL() ((void)0)
 #define STAMP_BEGIN() ((void)0)
 #define STAMP(slot, pred) ((void)0)
@@ -1924,6 +1970,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     sp.have = false; sp.mode = 0; sp.sigma_mu = 0.0; sp.alpha = 0.0;
 
     STAMP_DECL();
+    if (threadIdx.x == 0) MARK(21);
     // what a lane decides after sweep L of its problem (not in real-time-iteration mode's second call)
     auto after_L = [&]() {
         first = false;
@@ -2072,6 +2119,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             if (state == LS_FETCH) {
                 unsigned b = (unsigned)atomicAdd(counter, 1);
                 if (b >= B) {
+                    MARK(20);
                     state = LS_DONE;
                 } else {
                     L.b = b;
@@ -2162,7 +2210,10 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             }
             STAMP(1, st_b);
         }
-        if (!__any(state != LS_DONE)) break;
+        if (!__any(state != LS_DONE)) {
+            if (threadIdx.x == 0) MARK_LAST(22);
+            break;
+        }
 
         // ---- few problems left: one interior-point iteration of each, the wavefront on one problem
         const unsigned long long qp_mask = __ballot(state == LS_QP);
@@ -2253,6 +2304,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                 int k = best / boost_div;
                 if (k > budget) k = budget;
                 budget -= k;
+                if (threadIdx.x == 0 && best >= 1000) MARK(23);
                 for (int t = 0; t < k; ++t) {
                     const int st = __builtin_amdgcn_readlane(state, p);
                     if (st == LS_QP) single_qp(p);

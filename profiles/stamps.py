@@ -26,7 +26,7 @@ if ONLY >= 0:
 t0 = time.time()
 out = _lib.solve_packed(packed)
 dt = time.time() - t0
-NS = 32
+NS = 48
 buf = np.zeros((2048, NS), dtype=np.uint64)
 lib.mpcx_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.mpcx_debug_read_stamps(buf.ctypes.data, 1) == 0
@@ -37,6 +37,9 @@ cyc = buf[:, 0::2].astype(np.float64)
 cnt = buf[:, 1::2].astype(np.float64)
 used = cyc.sum(1) > 0
 print(f"B={B} wall {dt:.2f}s (incl. transfers); waves with work: {used.sum()}")
+mark_slots = [20, 21, 22, 23]
+marks_raw = cyc[:, mark_slots].copy()
+cyc[:, mark_slots] = 0
 tot = cyc[used].sum()
 ticks = None
 for i, n in enumerate(names):
@@ -46,3 +49,13 @@ print("cycles per wave (mean) %.3g" % cyc[used].sum(1).mean())
 w = cyc[used].sum(1)
 print("cycles per wave: min %.3g median %.3g p90 %.3g max %.3g" % (w.min(), np.median(w), np.percentile(w, 90), w.max()))
 print("qp_iter sum", int(out["qp_iter"].sum()), "sqp_iter sum", int(out["sqp_iter"].sum()))
+
+# wall-clock marks (100 MHz counter)
+t0 = marks_raw[used, 1].min()
+for name, col in (("start", 1), ("queue seen empty", 0), ("first extra iteration of a problem older than 1000", 3), ("exit", 2)):
+    v = marks_raw[used, col]
+    v = v[v > 0]
+    if v.size:
+        r = (v - t0) / 1e8
+        print(f"mark {name:52s} waves {v.size:5d}  min {r.min():.3f}s median {np.median(r):.3f}s "
+              f"p90 {np.percentile(r, 90):.3f}s max {r.max():.3f}s")
