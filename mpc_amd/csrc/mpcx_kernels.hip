@@ -1774,7 +1774,7 @@ __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_
 
 template <int NH, int NS, bool ONE>
 __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx_opts *op, double sigma_mu, ldouble *ret)
-    typedef Map<NH> M;
+{
     const mpcx_opts &o = *op;
     const int N = C.N;
     const int j = (int)threadIdx.x;
