@@ -1936,7 +1936,7 @@ enum LaneState {
 template <int NH>
 __global__ void __launch_bounds__(64)
 mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
-                int boost_min, int boost_div, int boost_cap)
+                int boost_min, int boost_div, int boost_cap, int boost_lanes)
 {
     const mpcx_opts &o = *op;
     typedef Map<NH> M;
@@ -2282,13 +2282,14 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         // ---- old problems get extra iterations, the wavefront on one problem at a time -------
         // A problem that has already taken many iterations is likely to take many more, and the
         // longest problem of a batch bounds its run time, so the extra iterations grow with the
-        // age: age / boost_div per tick of the wavefront, oldest first, boost_cap in total.
+        // age: age / boost_div per tick of the wavefront, oldest first, at most boost_lanes problems
+        // and boost_cap iterations in total.
         // They cost no HBM traffic (one problem's working set stays in L2), which is what the
         // other wavefronts are waiting for.
         if (boost_div > 0 && !o.rti) {
             int budget = boost_cap;
             unsigned long long seen = 0;
-            for (;;) {
+            for (int n_boosted = 0; n_boosted < boost_lanes; ++n_boosted) {
                 const int age = qp_total + ((state == LS_QP) ? qp_it : 0);
                 const bool cand = ((state == LS_QP) || (state == LS_LIN)) && age >= boost_min &&
                                   !((seen >> threadIdx.x) & 1ull);
@@ -2348,10 +2349,12 @@ size_t mpcx_stage_doubles(int nh)
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
                            double *workspace, int n_waves, int lanes, int coop_max, int lin_max, hipStream_t stream)
 {
-    int boost_min = 100, boost_div = 2, boost_cap = 4096;
-    if (const char *e = getenv("MPCX_BOOST")) {      // "min,div,cap"; div 0 switches the extra iterations off
-        int a = 0, b = 0, c = 0;
-        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a >= 0 && b >= 0 && c >= 0) { boost_min = a; boost_div = b; boost_cap = c; }
+    int boost_min = 100, boost_div = 2, boost_cap = 4096, boost_lanes = 1;
+    if (const char *e = getenv("MPCX_BOOST")) {      // "min,div,cap,lanes"; div 0 switches the extra iterations off
+        int a = 0, b = 0, c = 0, d = 1;
+        if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d) >= 3 && a >= 0 && b >= 0 && c >= 0 && d >= 0) {
+            boost_min = a; boost_div = b; boost_cap = c; boost_lanes = d;
+        }
     }
     int svc_min = MPCX_SERVICE_MIN;
     if (const char *e = getenv("MPCX_SVC_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) svc_min = v; }
@@ -2369,12 +2372,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     if (e != hipSuccess) return e;
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes); break;
 #else
     default: return hipErrorInvalidValue;
 #endif
