@@ -16,7 +16,6 @@
 
 namespace {
 
-constexpr int kMaxWaves = 2048;   // persistent 64-lane workgroups per launch (8 per CU on 256 CUs)
 
 thread_local char g_err[512] = "";
 
@@ -41,18 +40,31 @@ constexpr int kWavesPerCU = 4;    // resident wavefronts per CU the kernel's reg
 // How a batch is spread over persistent wavefronts.  Large batches fill every wavefront
 // (64 problems each, refilled from the queue).  Small ones are spread thin, down to one
 // problem per wavefront, because a wavefront with few problems finishes each of them
-// sooner; the spread is limited so that the workspace stays below kWorkspaceTarget.
-struct Plan { int waves, lanes, coop_max, lin_max; };
+// sooner; the spread is limited by the workspace it needs (`target` bytes; the default is sized
+// for a GPU with 288 GB, and the host entry point falls back to less if the allocation fails).
+struct Plan { int waves, lanes, coop_max, lin_max, coop_layout; };
 constexpr int kLinMax = 0;
 constexpr int kCoopMax = 8;     // problems per wavefront up to which the single-problem sweeps pay
-constexpr size_t kWorkspaceTarget = (size_t)8 << 30;
+constexpr int kPlanWaves = 1024;   // one wavefront per SIMD of 256 CUs; more would only wait for a slot
 
-Plan plan_for(int B, int N)
+size_t default_workspace_target()
 {
-    const size_t per_wave = (size_t)(N + 1) * mpcx_stage_doubles(MPCX_MAX_OBS) * 64 * sizeof(double);
-    size_t cap = kWorkspaceTarget / per_wave;
+    size_t gib = 64;
+    if (const char *e = std::getenv("MPCX_WORKSPACE_GIB")) {
+        const long v = std::atol(e);
+        if (v >= 1 && v <= 256) gib = (size_t)v;
+    }
+    return gib << 30;
+}
+
+size_t wave_bytes(int N, int nh) { return (size_t)(N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double); }
+
+Plan plan_for(int B, int N, size_t target)
+{
+    const size_t per_wave = wave_bytes(N, MPCX_MAX_OBS);
+    size_t cap = target / per_wave;
     if (cap < 1) cap = 1;
-    if (cap > (size_t)kMaxWaves) cap = kMaxWaves;
+    if (cap > (size_t)kPlanWaves) cap = kPlanWaves;
     Plan p;
     p.lanes = (int)(((size_t)B + cap - 1) / cap);
     // diagnostic knob: MPCX_LANES=n fixes the problems per wavefront (tests use it to run
@@ -72,6 +84,11 @@ Plan plan_for(int B, int N)
     if (const char *e = std::getenv("MPCX_LIN_MAX")) {
         const int v = std::atoi(e);
         if (v >= 0 && v <= 64) p.lin_max = v;
+    }
+    // few enough problems per wavefront to stay in single-problem mode throughout: per-problem layout
+    p.coop_layout = (p.coop_max > 0 && p.lanes <= p.coop_max && p.lanes * ((N + 64) / 64) <= N + 1) ? 1 : 0;
+    if (const char *e = std::getenv("MPCX_COOP_LAYOUT")) {
+        if (std::atoi(e) == 0) p.coop_layout = 0;
     }
     p.waves = (B + p.lanes - 1) / p.lanes;
     if (p.waves > (int)cap) p.waves = (int)cap;
@@ -149,7 +166,7 @@ int mpcx_device_count(void)
 size_t mpcx_workspace_bytes(int32_t B, int32_t N)
 {
     if (B <= 0 || N < 1) return 0;
-    return 512 + (size_t)plan_for(B, N).waves * (size_t)(N + 1) * mpcx_stage_doubles(MPCX_MAX_OBS) * 64 * sizeof(double);
+    return 512 + (size_t)plan_for(B, N, default_workspace_target()).waves * wave_bytes(N, MPCX_MAX_OBS);
 }
 
 int mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *out,
@@ -159,12 +176,14 @@ int mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts, mpcx_re
     if (in->B == 0) return 0;
     if (mpcx_device_count() <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
     const int nh = (opts->max_obs < 0) ? MPCX_MAX_OBS : opts->max_obs;
-    const Plan plan = plan_for(in->B, in->N);
-    const size_t need = 512 + (size_t)plan.waves * (size_t)(in->N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
-    if (!workspace || workspace_bytes < need)
-        return fail(MPCX_E_BADARG, "workspace too small: %zu bytes given, %zu needed", workspace_bytes, need);
+    // the batch is spread as far as the given workspace allows (mpcx_workspace_bytes() is the
+    // size that allows the widest useful spread); one wavefront's worth is the minimum
+    const size_t least = 512 + wave_bytes(in->N, MPCX_MAX_OBS);
+    if (!workspace || workspace_bytes < least)
+        return fail(MPCX_E_BADARG, "workspace too small: %zu bytes given, at least %zu needed", workspace_bytes, least);
+    const Plan plan = plan_for(in->B, in->N, workspace_bytes - 512);
     if ((uintptr_t)workspace % 256 != 0) return fail(MPCX_E_BADARG, "workspace not 256-byte aligned");
-    HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(workspace), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max,
+    HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(workspace), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, (opts->rti ? 0 : plan.coop_layout),
                             static_cast<hipStream_t>(stream)));
     return 0;
 }
@@ -193,16 +212,26 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
 
     const size_t n_pd = (size_t)MPCX_NFIELDS * B, n_xg = (N + 1) * MPCX_NX * B;
     const size_t n_X = B * (N + 1) * MPCX_NX, n_U = B * N * MPCX_NU;
-    const Plan plan = plan_for(in->B, in->N);
-    const size_t ws_bytes = 512 + (size_t)plan.waves * (N + 1) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
+    // the widest spread whose workspace can be allocated
+    DevBuf d_ws;
+    Plan plan;
+    size_t ws_bytes = 0;
+    for (size_t target = default_workspace_target();; target /= 2) {
+        plan = plan_for(in->B, in->N, target);
+        ws_bytes = 512 + (size_t)plan.waves * wave_bytes(in->N, nh);
+        if (d_ws.alloc(ws_bytes) == hipSuccess) break;
+        (void)hipGetLastError();
+        d_ws.p = nullptr;
+        if (plan.waves == 1 || target < ((size_t)1 << 28))
+            return fail(MPCX_E_NOMEM, "device allocation failed (workspace %zu bytes)", ws_bytes);
+    }
 
-    DevBuf d_pd, d_no, d_xg, d_ug, d_X, d_U, d_st, d_si, d_qi, d_co, d_re, d_ws;
+    DevBuf d_pd, d_no, d_xg, d_ug, d_X, d_U, d_st, d_si, d_qi, d_co, d_re;
     if (d_pd.alloc(n_pd * 8) != hipSuccess || d_no.alloc(B * 4) != hipSuccess ||
         d_xg.alloc(n_xg * 8) != hipSuccess || d_X.alloc(n_X * 8) != hipSuccess ||
         d_U.alloc(n_U * 8) != hipSuccess || d_st.alloc(B * 4) != hipSuccess ||
         d_si.alloc(B * 4) != hipSuccess || d_qi.alloc(B * 4) != hipSuccess ||
-        d_co.alloc(B * 8) != hipSuccess || d_re.alloc(4 * B * 8) != hipSuccess ||
-        d_ws.alloc(ws_bytes) != hipSuccess) {
+        d_co.alloc(B * 8) != hipSuccess || d_re.alloc(4 * B * 8) != hipSuccess) {
         (void)hipGetLastError();
         return fail(MPCX_E_NOMEM, "device allocation failed (workspace %zu bytes)", ws_bytes);
     }
@@ -230,7 +259,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     dout.cost = d_co.as<double>();
     dout.res = d_re.as<double>();
 
-    HIP_TRY(mpcx_launch_sqp(nh, din, o, dout, d_ws.as<double>(), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, nullptr));
+    HIP_TRY(mpcx_launch_sqp(nh, din, o, dout, d_ws.as<double>(), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, (o.rti ? 0 : plan.coop_layout), nullptr));
     HIP_TRY(hipDeviceSynchronize());
 
     HIP_TRY(hipMemcpy(out->X, d_X.p, n_X * 8, hipMemcpyDeviceToHost));

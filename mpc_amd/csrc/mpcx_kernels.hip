@@ -122,6 +122,9 @@ struct Lane {
     size_t B;
     unsigned lane;        // column of the workspace this lane works in, as a BYTE offset (8 * 0..63);
                           // in single-problem mode it also carries the offset of the lane's stage
+    unsigned region;      // 0: the workspace is laid out [stage][field][lane]; else the wavefront never
+                          // leaves single-problem mode and every problem has its own region of this
+                          // many bytes, laid out [block of 64 stages][field][stage in block]
     unsigned b;           // problem this lane is solving
     int N;
     int nobs;
@@ -1586,16 +1589,21 @@ DEV void coop_sync()
 DEV Lane stage_lane(const Lane &C, unsigned j)
 {
     Lane S = C;
-    S.lane = j * (unsigned)(C.F * 512) + C.lane;      // a wavefront's workspace is far below 4 GiB
+    // (a wavefront's workspace is far below 4 GiB)
+    if (C.region == 0) S.lane = j * (unsigned)(C.F * 512) + C.lane;
+    else S.lane = C.lane + (j >> 6) * (unsigned)(C.F * 512) + (j & 63u) * 8u;
     return S;
 }
+
+// where the data of the problem of lane p start: its column, or its region
+DEV unsigned problem_offset(const Lane &L, int p) { return (L.region == 0) ? 8u * (unsigned)p : L.region * (unsigned)p; }
 
 // the problem of lane p as wave-uniform values: C.lane = p is its column in the workspace
 template <int NH>
 DEV void problem_of_lane(const Lane &L, const PC<NH> &pc, ldouble *pc_lds, int p, Lane &C, PC<NH> &pcc)
 {
     C = L;
-    C.lane = 8u * (unsigned)p;
+    C.lane = problem_offset(L, p);
     C.b = (unsigned)__builtin_amdgcn_readlane((int)L.b, p);
     C.nobs = __builtin_amdgcn_readlane(L.nobs, p);
     C.h = bcast(L.h, p); C.hh = bcast(L.hh, p); C.h6 = bcast(L.h6, p);
@@ -1858,9 +1866,10 @@ __device__ __attribute__((noinline)) void coop_L(Lane C, PC<NH> pc, const mpcx_o
         if (kj < N) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                nxt[i] = ldw(S, 1, M::X + i);
-                nxt[NX + i] = ldw(S, 1, M::V + NU + i);
-                nxt[2 * NX + i] = ldw(S, 1, M::QPI + i);
+                const Lane S1 = stage_lane(C, (unsigned)kj + 1u);
+                nxt[i] = ldw(S1, 0, M::X + i);
+                nxt[NX + i] = ldw(S1, 0, M::V + NU + i);
+                nxt[2 * NX + i] = ldw(S1, 0, M::QPI + i);
             }
         }
         coop_sync();
@@ -1936,7 +1945,7 @@ enum LaneState {
 template <int NH>
 __global__ void __launch_bounds__(64)
 mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
-                int boost_min, int boost_div, int boost_cap, int boost_lanes)
+                int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout)
 {
     const mpcx_opts &o = *op;
     typedef Map<NH> M;
@@ -1955,6 +1964,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     L.pdata = (const gdouble *)in.pdata;
     L.B = (size_t)in.B;
     L.lane = 8u * threadIdx.x;
+    L.region = coop_layout ? (unsigned)(((N + 64) / 64) * M::F * 512) : 0u;
     L.b = 0;
     L.N = N;
     L.F = M::F;
@@ -2087,7 +2097,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                 const int p = __ffsll((long long)rest) - 1;
                 const size_t b = (unsigned)__builtin_amdgcn_readlane((int)L.b, p);
                 Lane C = L;
-                C.lane = 8u * (unsigned)p;
+                C.lane = problem_offset(L, p);
                 for (int k0 = 0; k0 <= N; k0 += 64) {
                     const int kj = k0 + (int)threadIdx.x;
                     if (kj > N) continue;
@@ -2154,7 +2164,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                 const int p = __ffsll((long long)rest) - 1;
                 const size_t b = (unsigned)__builtin_amdgcn_readlane((int)L.b, p);
                 Lane C = L;
-                C.lane = 8u * (unsigned)p;
+                C.lane = problem_offset(L, p);
                 for (int k0 = 0; k0 <= N; k0 += 64) {
                     const int kj = k0 + (int)threadIdx.x;
                     if (kj > N) continue;
@@ -2186,7 +2196,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             [[maybe_unused]] const bool st_b = (state == LS_LIN);
             // few problems in the wavefront: sweep L of each with a lane per stage
             const unsigned long long lin_mask = __ballot(state == LS_LIN);
-            const bool coop_lin = !o.rti && ((__popcll(lin_mask) + n_qp <= coop_max) || (__popcll(lin_mask) <= lin_max));
+            const bool coop_lin = (L.region != 0) ||
+                                  (!o.rti && ((__popcll(lin_mask) + n_qp <= coop_max) || (__popcll(lin_mask) <= lin_max)));
             if (coop_lin) {
                 for (unsigned long long rest = lin_mask; rest != 0; rest &= rest - 1) single_L(__ffsll((long long)rest) - 1);
                 coop_sync();      // what the stage lanes stored is visible to the problems' own lanes
@@ -2217,7 +2228,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
 
         // ---- few problems left: one interior-point iteration of each, the wavefront on one problem
         const unsigned long long qp_mask = __ballot(state == LS_QP);
-        if (__popcll(qp_mask) <= coop_max) {
+        if (__popcll(qp_mask) <= coop_max || L.region != 0) {
             for (unsigned long long rest = qp_mask; rest != 0; rest &= rest - 1) single_qp(__ffsll((long long)rest) - 1);
             coop_sync();      // every single-problem sweep starts with one; this one is for the other mode
             STAMP(11, state != LS_DONE);
@@ -2347,7 +2358,7 @@ size_t mpcx_stage_doubles(int nh)
 }
 
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
-                           double *workspace, int n_waves, int lanes, int coop_max, int lin_max, hipStream_t stream)
+                           double *workspace, int n_waves, int lanes, int coop_max, int lin_max, int coop_layout, hipStream_t stream)
 {
     int boost_min = 100, boost_div = 2, boost_cap = 4096, boost_lanes = 1;
     if (const char *e = getenv("MPCX_BOOST")) {      // "min,div,cap,lanes"; div 0 switches the extra iterations off
@@ -2372,12 +2383,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     if (e != hipSuccess) return e;
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout); break;
 #else
     default: return hipErrorInvalidValue;
 #endif
