@@ -12,7 +12,9 @@ size_t mpcx_stage_doubles(int nh);
 
 // Launch the fused SQP solve on `n_waves` persistent 64-lane workgroups.  All
 // pointers inside `in` / `out` and `workspace` are device memory; `workspace`
-// holds 512 bytes (problem counter, options) + n_waves * (N+1) * mpcx_stage_doubles(nh) * 64 doubles.
+// holds 512 bytes (problem counter, options) + n_waves * ((N+1) + slots * ceil((N+1)/64)) *
+// mpcx_stage_doubles(nh) * 64 doubles: per wavefront N+1 stage records for 64 problems, then `slots`
+// regions to which its last problems are moved once the queue is empty (stages contiguous).
 // Each wavefront works on at most `lanes` (1..64) problems at a time; with `coop_max` or fewer
 // of them in progress it takes them one at a time, a lane per stage (0 = never); sweep L is
 // done that way whenever `lin_max` or fewer problems of the wavefront wait for it.
@@ -20,7 +22,7 @@ size_t mpcx_stage_doubles(int nh);
 // lanes * ceil((N+1)/64) <= N+1): the wavefront never runs the one-lane-per-problem sweeps and its
 // workspace is laid out per problem, stages contiguous, so that its accesses coalesce.
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
-                           double *workspace, int n_waves, int lanes, int coop_max, int lin_max, int coop_layout, hipStream_t stream);
+                           double *workspace, int n_waves, int lanes, int coop_max, int lin_max, int coop_layout, int slots, hipStream_t stream);
 
 // sin/cos exactly as the solver computes them (arithmetic parity tests)
 hipError_t mpcx_launch_probe(const double *xin, int n, double *s, double *c, hipStream_t stream);

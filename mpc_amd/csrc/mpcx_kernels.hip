@@ -125,6 +125,8 @@ struct Lane {
     unsigned region;      // 0: the workspace is laid out [stage][field][lane]; else the wavefront never
                           // leaves single-problem mode and every problem has its own region of this
                           // many bytes, laid out [block of 64 stages][field][stage in block]
+    unsigned roff;        // not 0: this lane's problem has been moved to a region of its own (same
+                          // layout as above) that starts at this byte offset of the wavefront's workspace
     unsigned b;           // problem this lane is solving
     int N;
     int nobs;
@@ -1595,15 +1597,23 @@ DEV Lane stage_lane(const Lane &C, unsigned j)
     return S;
 }
 
-// where the data of the problem of lane p start: its column, or its region
-DEV unsigned problem_offset(const Lane &L, int p) { return (L.region == 0) ? 8u * (unsigned)p : L.region * (unsigned)p; }
+DEV unsigned region_bytes(const Lane &L) { return (unsigned)(((L.N + 64) / 64) * L.F * 512); }
+
+// C = L addressed at the data of the problem of lane p: its column, or its region
+DEV void problem_home(const Lane &L, int p, Lane &C)
+{
+    C = L;
+    const unsigned r = (unsigned)__builtin_amdgcn_readlane((int)L.roff, p);
+    if (r != 0) { C.lane = r; C.region = region_bytes(L); }
+    else C.lane = (L.region == 0) ? 8u * (unsigned)p : L.region * (unsigned)p;
+    C.roff = 0;
+}
 
 // the problem of lane p as wave-uniform values: C.lane = p is its column in the workspace
 template <int NH>
 DEV void problem_of_lane(const Lane &L, const PC<NH> &pc, ldouble *pc_lds, int p, Lane &C, PC<NH> &pcc)
 {
-    C = L;
-    C.lane = problem_offset(L, p);
+    problem_home(L, p, C);
     C.b = (unsigned)__builtin_amdgcn_readlane((int)L.b, p);
     C.nobs = __builtin_amdgcn_readlane(L.nobs, p);
     C.h = bcast(L.h, p); C.hh = bcast(L.hh, p); C.h6 = bcast(L.h6, p);
@@ -1945,13 +1955,14 @@ enum LaneState {
 template <int NH>
 __global__ void __launch_bounds__(64)
 mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
-                int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout)
+                int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots)
 {
     const mpcx_opts &o = *op;
     typedef Map<NH> M;
     const int N = in.N;
     const unsigned B = (unsigned)in.B;
-    const size_t wave_doubles = (size_t)(N + 1) * M::F * 64;
+    // stage records of the [stage][field][lane] layout, then `slots` single-problem regions
+    const size_t wave_doubles = (size_t)((N + 1) + slots * ((N + 64) / 64)) * M::F * 64;
 
     __shared__ double pc_lds[(PCN<NH>::N + 6) * 64];      // constants, 5 result slots, carry words
     PC<NH> pc;
@@ -1965,6 +1976,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     L.B = (size_t)in.B;
     L.lane = 8u * threadIdx.x;
     L.region = coop_layout ? (unsigned)(((N + 64) / 64) * M::F * 512) : 0u;
+    L.roff = 0;
     L.b = 0;
     L.N = N;
     L.F = M::F;
@@ -2080,8 +2092,44 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         }
     };
 
+    bool moved = false;      // the last problems of this wavefront have been moved to regions of their own
     for (;;) {
         STAMP_BEGIN();
+        // ---- the queue is empty and few problems are left: from here on the wavefront stays in
+        // single-problem mode, so each problem is moved to a region where its stages are contiguous
+        if (!moved && slots > 0 && L.region == 0 && !o.rti &&
+            __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)B) {
+            const bool active = (state == LS_QP) || (state == LS_LIN) || (state == LS_OUT);
+            const unsigned long long amask = __ballot(active);
+            if (__popcll(amask) <= slots && __popcll(amask) <= coop_max) {
+                moved = true;
+                coop_sync();
+                int slot = 0;
+                for (unsigned long long rest = amask; rest != 0; rest &= rest - 1, ++slot) {
+                    const int p = __ffsll((long long)rest) - 1;
+                    Lane C;
+                    problem_home(L, p, C);
+                    Lane R = C;
+                    R.region = region_bytes(L);
+                    R.lane = (unsigned)((N + 1) + slot * ((N + 64) / 64)) * (unsigned)(M::F * 512);
+                    for (int k0 = 0; k0 <= N; k0 += 64) {
+                        const int kj = k0 + (int)threadIdx.x;
+                        if (kj > N) continue;
+                        const Lane S = stage_lane(C, (unsigned)kj), D = stage_lane(R, (unsigned)kj);
+                        for (int f0 = 0; f0 < M::F; f0 += 16) {
+                            double tmp[16];
+#pragma unroll
+                            for (int f = 0; f < 16; ++f) tmp[f] = (f0 + f < M::F) ? ldw(S, 0, f0 + f) : 0.0;
+#pragma unroll
+                            for (int f = 0; f < 16; ++f)
+                                if (f0 + f < M::F) stw(D, 0, f0 + f, tmp[f]);
+                        }
+                    }
+                    if ((int)threadIdx.x == p) L.roff = R.lane;
+                }
+                coop_sync();
+            }
+        }
         // ---- service: results out, next problem in, new SQP iteration ---------------------
         const bool wants = (state == LS_OUT) || (state == LS_FETCH) || (state == LS_LIN);
         const int n_wants = __popcll(__ballot(wants));
@@ -2096,8 +2144,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             for (unsigned long long rest = out_mask; rest != 0; rest &= rest - 1) {
                 const int p = __ffsll((long long)rest) - 1;
                 const size_t b = (unsigned)__builtin_amdgcn_readlane((int)L.b, p);
-                Lane C = L;
-                C.lane = problem_offset(L, p);
+                Lane C;
+                problem_home(L, p, C);
                 for (int k0 = 0; k0 <= N; k0 += 64) {
                     const int kj = k0 + (int)threadIdx.x;
                     if (kj > N) continue;
@@ -2133,6 +2181,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                     state = LS_DONE;
                 } else {
                     L.b = b;
+                    L.roff = 0;
                     int nobs = in.n_obs ? in.n_obs[b] : 0;
                     if (nobs < 0 || nobs > NH) {     // the host validates; stay memory safe regardless
                         out.status[b] = MPCX_NAN;
@@ -2163,8 +2212,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             for (unsigned long long rest = new_mask; rest != 0; rest &= rest - 1) {
                 const int p = __ffsll((long long)rest) - 1;
                 const size_t b = (unsigned)__builtin_amdgcn_readlane((int)L.b, p);
-                Lane C = L;
-                C.lane = problem_offset(L, p);
+                Lane C;
+                problem_home(L, p, C);
                 for (int k0 = 0; k0 <= N; k0 += 64) {
                     const int kj = k0 + (int)threadIdx.x;
                     if (kj > N) continue;
@@ -2358,7 +2407,7 @@ size_t mpcx_stage_doubles(int nh)
 }
 
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
-                           double *workspace, int n_waves, int lanes, int coop_max, int lin_max, int coop_layout, hipStream_t stream)
+                           double *workspace, int n_waves, int lanes, int coop_max, int lin_max, int coop_layout, int slots, hipStream_t stream)
 {
     int boost_min = 100, boost_div = 2, boost_cap = 4096, boost_lanes = 1;
     if (const char *e = getenv("MPCX_BOOST")) {      // "min,div,cap,lanes"; div 0 switches the extra iterations off
@@ -2383,12 +2432,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     if (e != hipSuccess) return e;
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots); break;
 #else
     default: return hipErrorInvalidValue;
 #endif
