@@ -45,6 +45,7 @@ constexpr int kWavesPerCU = 4;    // resident wavefronts per CU the kernel's reg
 struct Plan { int waves, lanes, coop_max, lin_max, coop_layout; };
 constexpr int kLinMax = 0;
 constexpr int kCoopMax = 8;     // problems per wavefront up to which the single-problem sweeps pay
+constexpr int kSlots = 8;        // regions per wavefront for problems worked on in single-problem mode only
 constexpr int kPlanWaves = 1024;   // one wavefront per SIMD of 256 CUs; more would only wait for a slot
 
 size_t default_workspace_target()
@@ -57,11 +58,11 @@ size_t default_workspace_target()
     return gib << 30;
 }
 
-// a wavefront's workspace: N+1 stage records for 64 problems, then kCoopMax regions of
+// a wavefront's workspace: N+1 stage records for 64 problems, then kSlots regions of
 // ceil((N+1)/64) records each, one per problem, for the last problems of the wavefront
 size_t wave_bytes(int N, int nh)
 {
-    return (size_t)((N + 1) + kCoopMax * ((N + 64) / 64)) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
+    return (size_t)((N + 1) + kSlots * ((N + 64) / 64)) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
 }
 
 Plan plan_for(int B, int N, size_t target)
@@ -188,7 +189,7 @@ int mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts, mpcx_re
         return fail(MPCX_E_BADARG, "workspace too small: %zu bytes given, at least %zu needed", workspace_bytes, least);
     const Plan plan = plan_for(in->B, in->N, workspace_bytes - 512);
     if ((uintptr_t)workspace % 256 != 0) return fail(MPCX_E_BADARG, "workspace not 256-byte aligned");
-    HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(workspace), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, (opts->rti ? 0 : plan.coop_layout), kCoopMax,
+    HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(workspace), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, (opts->rti ? 0 : plan.coop_layout), kSlots,
                             static_cast<hipStream_t>(stream)));
     return 0;
 }
@@ -264,7 +265,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     dout.cost = d_co.as<double>();
     dout.res = d_re.as<double>();
 
-    HIP_TRY(mpcx_launch_sqp(nh, din, o, dout, d_ws.as<double>(), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, (o.rti ? 0 : plan.coop_layout), kCoopMax, nullptr));
+    HIP_TRY(mpcx_launch_sqp(nh, din, o, dout, d_ws.as<double>(), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, (o.rti ? 0 : plan.coop_layout), kSlots, nullptr));
     HIP_TRY(hipDeviceSynchronize());
 
     HIP_TRY(hipMemcpy(out->X, d_X.p, n_X * 8, hipMemcpyDeviceToHost));

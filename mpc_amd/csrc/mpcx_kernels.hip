@@ -2092,7 +2092,42 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         }
     };
 
-    bool moved = false;      // the last problems of this wavefront have been moved to regions of their own
+    // Regions: `slots` per wavefront, behind the stage records.  A problem that the wavefront will
+    // only work on in single-problem mode from now on is moved to a free one (`solo` lane): the
+    // last problems once the queue is empty, and old problems that get extra iterations.
+    bool moved = false;          // the queue is empty and the last problems have been moved
+    bool solo = false;           // this lane's problem lives in a region; the one-lane-per-problem sweeps skip it
+    unsigned slot_used = 0;      // same in all lanes
+    const unsigned rec_bytes = (unsigned)(M::F * 512), nblk = (unsigned)((N + 64) / 64);
+    auto move_to_region = [&](int p) -> bool {
+        if (__builtin_amdgcn_readlane((int)L.roff, p) != 0) return true;
+        const unsigned free_slots = ~slot_used & ((slots >= 32) ? 0xffffffffu : ((1u << slots) - 1u));
+        if (free_slots == 0) return false;
+        const int slot = __ffs((int)free_slots) - 1;
+        slot_used |= 1u << slot;
+        Lane C;
+        problem_home(L, p, C);
+        Lane R = C;
+        R.region = region_bytes(L);
+        R.lane = ((unsigned)(N + 1) + (unsigned)slot * nblk) * rec_bytes;
+        coop_sync();
+        for (int k0 = 0; k0 <= N; k0 += 64) {
+            const int kj = k0 + (int)threadIdx.x;
+            if (kj > N) continue;
+            const Lane S = stage_lane(C, (unsigned)kj), D = stage_lane(R, (unsigned)kj);
+            for (int f0 = 0; f0 < M::F; f0 += 16) {
+                double tmp[16];
+#pragma unroll
+                for (int f = 0; f < 16; ++f) tmp[f] = (f0 + f < M::F) ? ldw(S, 0, f0 + f) : 0.0;
+#pragma unroll
+                for (int f = 0; f < 16; ++f)
+                    if (f0 + f < M::F) stw(D, 0, f0 + f, tmp[f]);
+            }
+        }
+        if ((int)threadIdx.x == p) { L.roff = R.lane; solo = true; }
+        coop_sync();
+        return true;
+    };
     for (;;) {
         STAMP_BEGIN();
         // ---- the queue is empty and few problems are left: from here on the wavefront stays in
@@ -2103,31 +2138,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             const unsigned long long amask = __ballot(active);
             if (__popcll(amask) <= slots && __popcll(amask) <= coop_max) {
                 moved = true;
-                coop_sync();
-                int slot = 0;
-                for (unsigned long long rest = amask; rest != 0; rest &= rest - 1, ++slot) {
-                    const int p = __ffsll((long long)rest) - 1;
-                    Lane C;
-                    problem_home(L, p, C);
-                    Lane R = C;
-                    R.region = region_bytes(L);
-                    R.lane = (unsigned)((N + 1) + slot * ((N + 64) / 64)) * (unsigned)(M::F * 512);
-                    for (int k0 = 0; k0 <= N; k0 += 64) {
-                        const int kj = k0 + (int)threadIdx.x;
-                        if (kj > N) continue;
-                        const Lane S = stage_lane(C, (unsigned)kj), D = stage_lane(R, (unsigned)kj);
-                        for (int f0 = 0; f0 < M::F; f0 += 16) {
-                            double tmp[16];
-#pragma unroll
-                            for (int f = 0; f < 16; ++f) tmp[f] = (f0 + f < M::F) ? ldw(S, 0, f0 + f) : 0.0;
-#pragma unroll
-                            for (int f = 0; f < 16; ++f)
-                                if (f0 + f < M::F) stw(D, 0, f0 + f, tmp[f]);
-                        }
-                    }
-                    if ((int)threadIdx.x == p) L.roff = R.lane;
-                }
-                coop_sync();
+                for (unsigned long long rest = amask; rest != 0; rest &= rest - 1)
+                    (void)move_to_region(__ffsll((long long)rest) - 1);
             }
         }
         // ---- service: results out, next problem in, new SQP iteration ---------------------
@@ -2162,8 +2174,18 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                     }
                 }
             }
+            {
+                // regions of the problems just written out are free again
+                const unsigned long long freed = __ballot(state == LS_OUT && L.roff != 0);
+                for (unsigned long long rest = freed; rest != 0; rest &= rest - 1) {
+                    const unsigned r = (unsigned)__builtin_amdgcn_readlane((int)L.roff, __ffsll((long long)rest) - 1);
+                    slot_used &= ~(1u << ((r / rec_bytes - (unsigned)(N + 1)) / nblk));
+                }
+            }
             if (state == LS_OUT) {
                 const size_t b = L.b;
+                L.roff = 0;
+                solo = false;
                 out.status[b] = status;
                 out.sqp_iter[b] = sqp_it;
                 out.qp_iter[b] = qp_total;
@@ -2247,8 +2269,9 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             const unsigned long long lin_mask = __ballot(state == LS_LIN);
             const bool coop_lin = (L.region != 0) ||
                                   (!o.rti && ((__popcll(lin_mask) + n_qp <= coop_max) || (__popcll(lin_mask) <= lin_max)));
-            if (coop_lin) {
-                for (unsigned long long rest = lin_mask; rest != 0; rest &= rest - 1) single_L(__ffsll((long long)rest) - 1);
+            const unsigned long long single_mask = coop_lin ? lin_mask : (lin_mask & __ballot(solo));
+            if (single_mask != 0) {
+                for (unsigned long long rest = single_mask; rest != 0; rest &= rest - 1) single_L(__ffsll((long long)rest) - 1);
                 coop_sync();      // what the stage lanes stored is visible to the problems' own lanes
             }
             if (state == LS_LIN) {
@@ -2259,7 +2282,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                     status = MPCX_SUCCESS;
                     state = LS_OUT;
                 } else {
-                    if (!coop_lin) {
+                    if (!coop_lin && !solo) {
                         sweep_L<NH>(L, pc, op, first, ret);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) res[i] = ret[i * 64];
@@ -2285,9 +2308,9 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         }
 
         // ---- one interior-point iteration ---------------------------------------------------
-        [[maybe_unused]] const bool st_c = (state == LS_QP);
+        [[maybe_unused]] const bool st_c = (state == LS_QP) && !solo;
         bool iterate = false;
-        if (state == LS_QP) {
+        if (state == LS_QP && !solo) {
             sweep_B0<NH>(L, pc, op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, m_total, ret);
             const double Rg = ret[0 * 64], Rb = ret[1 * 64], Rd = ret[2 * 64], Rm = ret[3 * 64];
             int qs = -1;     // HPIPM-style: 0 solved, 1 iteration limit, 3 NaN
@@ -2347,23 +2370,34 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         // They cost no HBM traffic (one problem's working set stays in L2), which is what the
         // other wavefronts are waiting for.
         if (boost_div > 0 && !o.rti) {
-            int budget = boost_cap;
+            int budget = boost_cap, n_new = 0;
             unsigned long long seen = 0;
-            for (int n_boosted = 0; n_boosted < boost_lanes; ++n_boosted) {
+            for (;;) {
                 const int age = qp_total + ((state == LS_QP) ? qp_it : 0);
-                const bool cand = ((state == LS_QP) || (state == LS_LIN)) && age >= boost_min &&
-                                  !((seen >> threadIdx.x) & 1ull);
-                const unsigned long long cm = __ballot(cand);
-                if (cm == 0 || budget <= 0) break;
+                const bool live = ((state == LS_QP) || (state == LS_LIN)) && !((seen >> threadIdx.x) & 1ull);
+                // problems in regions take all their iterations here; of the others, the oldest
+                // boost_lanes (they move to a region if one is free)
+                const unsigned long long sm = __ballot(live && solo);
+                const unsigned long long cm = (n_new < boost_lanes) ? __ballot(live && !solo && age >= boost_min) : 0ull;
+                if ((sm | cm) == 0) break;
                 int p = -1, best = -1;
-                for (unsigned long long rest = cm; rest != 0; rest &= rest - 1) {
-                    const int i = __ffsll((long long)rest) - 1;
-                    const int a = __builtin_amdgcn_readlane(age, i);
-                    if (a > best) { best = a; p = i; }
+                if (sm != 0) {
+                    p = __ffsll((long long)sm) - 1;
+                    best = __builtin_amdgcn_readlane(age, p);
+                } else {
+                    if (budget <= 0) break;
+                    for (unsigned long long rest = cm; rest != 0; rest &= rest - 1) {
+                        const int i = __ffsll((long long)rest) - 1;
+                        const int a = __builtin_amdgcn_readlane(age, i);
+                        if (a > best) { best = a; p = i; }
+                    }
+                    ++n_new;
+                    if (slots > 0 && L.region == 0) (void)move_to_region(p);
                 }
                 seen |= 1ull << p;
                 int k = best / boost_div;
                 if (k > budget) k = budget;
+                if (k < 1) k = 1;
                 budget -= k;
                 if (threadIdx.x == 0 && best >= 1000) MARK(23);
                 for (int t = 0; t < k; ++t) {
@@ -2409,13 +2443,14 @@ size_t mpcx_stage_doubles(int nh)
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
                            double *workspace, int n_waves, int lanes, int coop_max, int lin_max, int coop_layout, int slots, hipStream_t stream)
 {
-    int boost_min = 100, boost_div = 2, boost_cap = 4096, boost_lanes = 1;
+    int boost_min = 16, boost_div = 1, boost_cap = 8192, boost_lanes = 4;
     if (const char *e = getenv("MPCX_BOOST")) {      // "min,div,cap,lanes"; div 0 switches the extra iterations off
         int a = 0, b = 0, c = 0, d = 1;
         if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d) >= 3 && a >= 0 && b >= 0 && c >= 0 && d >= 0) {
             boost_min = a; boost_div = b; boost_cap = c; boost_lanes = d;
         }
     }
+    if (const char *e = getenv("MPCX_SLOTS")) { int v = atoi(e); if (v >= 0 && v <= slots) slots = v; }   // fewer only
     int svc_min = MPCX_SERVICE_MIN;
     if (const char *e = getenv("MPCX_SVC_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) svc_min = v; }
     if (coop_max < 0 || coop_max > 64) return hipErrorInvalidValue;
