@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 101
+#define MPCX_VERSION 102
 
 #define MPCX_NX 5       /* state  [x, y, theta, v, delta]        (core_solver.py:131) */
 #define MPCX_NU 2       /* input  [acceleration, steering rate]  (core_solver.py:132) */
@@ -133,6 +133,21 @@ size_t mpcx_workspace_bytes(int32_t B, int32_t N);
 int    mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts,
                                mpcx_result *out, void *workspace,
                                size_t workspace_bytes, void *stream);
+
+/*
+ * Initial state guess of core_solver.py:477-499 for problems WITHOUT obstacles (its obstacle
+ * branch, adjust_point_for_obstacles :360-473, stays on the host), computed on the device from
+ * the problem table: node i gets the start-goal interpolation at t = i/N, y clamped to the
+ * reference's centre-line formula +- width/2, heading interpolated, v = 1 - t, delta = 0;
+ * node N gets the goal state.  Same operations in the same order as the host loop, so the
+ * result is bit-identical to it.  width[b] = EgoConfig.corridor_width (core_solver.py:27).
+ * _device: pdata [MPCX_NFIELDS][B], width [B], xguess [N+1][5][B] are device pointers and the
+ * kernel is queued on `stream`; the other form takes host pointers and device `device`.
+ */
+int mpcx_initial_guess_device(const double *pdata, const double *width, int32_t B, int32_t N,
+                              double *xguess, void *stream);
+int mpcx_initial_guess(const double *pdata, const double *width, int32_t B, int32_t N,
+                       double *xguess, int device);
 
 /*
  * Diagnostic, no counterpart in the reference: sin and cos of n host doubles,

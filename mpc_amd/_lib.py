@@ -73,6 +73,10 @@ def load_library(path=None):
                                             C.POINTER(MpcxResult), C.c_void_p,
                                             C.c_size_t, C.c_void_p]
     lib.mpcx_solve_batch_device.restype = C.c_int
+    lib.mpcx_initial_guess_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.mpcx_initial_guess_device.restype = C.c_int
+    lib.mpcx_initial_guess.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int]
+    lib.mpcx_initial_guess.restype = C.c_int
     lib.mpcx_probe_sincos.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int]
     lib.mpcx_probe_sincos.restype = C.c_int
     if path is None:
@@ -136,4 +140,19 @@ def solve_packed(packed, opts=None, device=0):
     r = result_struct(out)
     _check(lib, lib.mpcx_solve_batch(C.byref(b), C.byref(opts), C.byref(r), int(device)),
            "mpcx_solve_batch")
+    return out
+
+
+def initial_guess_on_device(pdata, width, N, device=0):
+    """xguess [N+1, 5, B] of obstacle-free problems computed on HIP device ``device`` from the
+    problem table (host arrays in, host array out); bit-identical to batch.initial_guess_batch."""
+    lib = load_library()
+    if lib.mpcx_device_count() <= 0:
+        raise MpcxError("no HIP device available (there is no CPU fallback)")
+    pdata = np.ascontiguousarray(pdata, dtype=np.float64)
+    width = np.ascontiguousarray(width, dtype=np.float64)
+    B = pdata.shape[1]
+    out = np.empty((N + 1, 5, B), dtype=np.float64)
+    _check(lib, lib.mpcx_initial_guess(pdata.ctypes.data, width.ctypes.data, B, N, out.ctypes.data, int(device)),
+           "mpcx_initial_guess")
     return out

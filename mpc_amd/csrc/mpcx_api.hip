@@ -280,6 +280,42 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
 
 // arithmetic probe used by the parity tests: sin/cos of n host doubles as the
 // solver computes them on the device
+int mpcx_initial_guess_device(const double *pdata, const double *width, int32_t B, int32_t N,
+                              double *xguess, void *stream)
+{
+    if (B < 0 || N < 1) return fail(MPCX_E_BADARG, "need B >= 0 and N >= 1 (B=%d, N=%d)", B, N);
+    if (B == 0) return 0;
+    if (!pdata || !width || !xguess) return fail(MPCX_E_BADARG, "null argument");
+    if (mpcx_device_count() <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
+    HIP_TRY(mpcx_launch_guess(pdata, width, B, N, xguess, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int mpcx_initial_guess(const double *pdata, const double *width, int32_t B, int32_t N,
+                       double *xguess, int device)
+{
+    if (B < 0 || N < 1) return fail(MPCX_E_BADARG, "need B >= 0 and N >= 1 (B=%d, N=%d)", B, N);
+    if (B == 0) return 0;
+    if (!pdata || !width || !xguess) return fail(MPCX_E_BADARG, "null argument");
+    const int ndev = mpcx_device_count();
+    if (ndev <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(MPCX_E_BADARG, "device %d out of range [0, %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    const size_t n_pd = (size_t)MPCX_NFIELDS * B, n_xg = (size_t)(N + 1) * MPCX_NX * B;
+    DevBuf d_pd, d_w, d_xg;
+    if (d_pd.alloc(n_pd * 8) != hipSuccess || d_w.alloc((size_t)B * 8) != hipSuccess ||
+        d_xg.alloc(n_xg * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(MPCX_E_NOMEM, "device allocation failed");
+    }
+    HIP_TRY(hipMemcpy(d_pd.p, pdata, n_pd * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_w.p, width, (size_t)B * 8, hipMemcpyHostToDevice));
+    HIP_TRY(mpcx_launch_guess(d_pd.as<double>(), d_w.as<double>(), B, N, d_xg.as<double>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(xguess, d_xg.p, n_xg * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int mpcx_probe_sincos(const double *x, int32_t n, double *s, double *c, int device)
 {
     if (!x || !s || !c || n < 0) return fail(MPCX_E_BADARG, "bad probe arguments");

@@ -24,6 +24,9 @@ size_t mpcx_stage_doubles(int nh);
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
                            double *workspace, int n_waves, int lanes, int coop_max, int lin_max, int coop_layout, int slots, hipStream_t stream);
 
+// initial guess of obstacle-free problems from the problem table (device pointers)
+hipError_t mpcx_launch_guess(const double *pdata, const double *width, int B, int N, double *xguess, hipStream_t stream);
+
 // sin/cos exactly as the solver computes them (arithmetic parity tests)
 hipError_t mpcx_launch_probe(const double *xin, int n, double *s, double *c, hipStream_t stream);
 

@@ -2417,6 +2417,43 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     }
 }
 
+// initial guess without obstacles (reference core_solver.py:477-499): one thread per problem,
+// node by node; every store of a wavefront is one contiguous segment of xguess[i][c][:]
+__global__ void mpcx_guess_kernel(const double *pdata, const double *width, int B, int N, double *xguess)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t Bs = (size_t)B;
+    double s[NX], g[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        s[i] = pdata[(size_t)(MPCX_F_X0 + i) * Bs + b];
+        g[i] = pdata[(size_t)(MPCX_F_GOAL + i) * Bs + b];
+    }
+    // corridor rows are stored as (-a1, -c1, a2, c2) and (b1, -b2)
+    const double a = pdata[(size_t)(MPCX_F_CG + 2) * Bs + b];
+    const double b1 = pdata[(size_t)(MPCX_F_UG + 0) * Bs + b];
+    const double b2 = -pdata[(size_t)(MPCX_F_UG + 1) * Bs + b];
+    const double half = width[b] / 2;
+    for (int i = 0; i < N; ++i) {
+        const double t = (double)i / (double)N;
+        const double x = s[0] + t * (g[0] - s[0]);
+        double y = s[1] + t * (g[1] - s[1]);
+        const double yc = -(((a * x + b1 / 2) + a * x) + b2 / 2) / 2;
+        const double lo = yc - half, hi = yc + half;
+        y = (y > lo) ? y : lo;
+        y = (y < hi) ? y : hi;
+        double *o = xguess + (size_t)i * NX * Bs + b;
+        o[0 * Bs] = x;
+        o[1 * Bs] = y;
+        o[2 * Bs] = s[2] + t * (g[2] - s[2]);
+        o[3 * Bs] = 1.0 * (1 - t);
+        o[4 * Bs] = 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < NX; ++c) xguess[((size_t)N * NX + c) * Bs + b] = g[c];
+}
+
 // sin/cos as the solver computes them, for the arithmetic parity tests
 __global__ void mpcx_probe_kernel(const double *xin, int n, double *s, double *c)
 {
@@ -2491,6 +2528,12 @@ extern "C" int mpcx_debug_read_stamps(unsigned long long *out, int reset)
     return 0;
 }
 #endif
+
+hipError_t mpcx_launch_guess(const double *pdata, const double *width, int B, int N, double *xguess, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mpcx_guess_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, pdata, width, B, N, xguess);
+    return hipGetLastError();
+}
 
 hipError_t mpcx_launch_probe(const double *xin, int n, double *s, double *c, hipStream_t stream)
 {

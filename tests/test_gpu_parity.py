@@ -189,3 +189,18 @@ def test_edge_shapes_match_oracle(oracle, monkeypatch):
     # empty batch
     out = _lib.solve_packed(packed.slice(0, 0))
     assert out["X"].shape == (0, packed.N + 1, 5) and out["status"].shape == (0,)
+
+
+def test_device_initial_guess_is_the_host_loop():
+    """The guess computed on the device from the problem table equals the host restatement of
+    reference core_solver.py:477-499 bit for bit (obstacle-free problems)."""
+    from mpc_amd.batch import pack_arrays
+    rng = np.random.default_rng(4)
+    B = 5000
+    start = rng.uniform(-30, 30, (B, 5)); goal = rng.uniform(-30, 30, (B, 5))
+    start[:, 2] = rng.uniform(-4, 4, B); goal[:, 2] = rng.uniform(-4, 4, B)
+    for duration, width in ((5.0, 15.0), (12.3, 2.0)):
+        packed = pack_arrays(start, goal, duration, corridor_width=width)
+        got = _lib.initial_guess_on_device(packed.pdata, np.full(B, width), packed.N)
+        assert got.shape == packed.xguess.shape
+        assert np.array_equal(got, packed.xguess)
