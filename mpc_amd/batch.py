@@ -225,11 +225,20 @@ def pack_problems(egos, sim_cfg):
     pdata = np.zeros((NFIELDS, B), dtype=np.float64)
     n_obs = np.zeros(B, dtype=np.int32)
     xguess = np.empty((N + 1, NX, B), dtype=np.float64)
+    width = np.empty(B, dtype=np.float64)
     for b, ego in enumerate(egos):
         col, nb, corridor = _ego_fields(ego, N, sim_cfg.duration)
         pdata[:, b] = col
         n_obs[b] = nb
-        xguess[:, :, b] = initial_guess(ego, N, corridor)
+        width[b] = ego.corridor_width
+        if nb > 0:      # the obstacle branch of the guess is a scalar loop
+            xguess[:, :, b] = initial_guess(ego, N, corridor)
+    free = np.nonzero(n_obs == 0)[0]
+    if free.size:
+        # obstacle-free problems: the same operations, all problems at once
+        xguess[:, :, free] = initial_guess_batch(
+            pdata[F_X0:F_X0 + 5, free].T, pdata[F_GOAL:F_GOAL + 5, free].T, width[free], N,
+            pdata[F_CG + 2, free], pdata[F_UG, free], -pdata[F_UG + 1, free])
     return PackedBatch(B, N, pdata, n_obs, xguess, float(sim_cfg.duration))
 
 
