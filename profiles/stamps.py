@@ -20,7 +20,14 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 ONLY = int(sys.argv[2]) if len(sys.argv) > 2 else -1        # solve just this problem of the batch
 lib = _lib.load_library(os.path.join(ROOT, "mpc_amd", "csrc", "libmpcx_stamps.so"))
 _lib._lib = lib
-packed = synthetic_batch(B)
+if os.environ.get("STAMPS_GRID"):
+    # the reference's 32-pose grid sweep at N = 800 instead of the synthetic batch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    from mpc_amd.batch import pack_problems
+    packed = pack_problems(*cases.grid_problems())
+else:
+    packed = synthetic_batch(B)
 if ONLY >= 0:
     packed = packed.slice(ONLY, ONLY + 1)
 t0 = time.time()

@@ -60,3 +60,20 @@ def test_bad_arguments_and_no_device():
         assert lib.mpcx_solve_batch(C.byref(b), C.byref(o), C.byref(r), 0) == -2      # MPCX_E_NODEVICE
         x = np.zeros(4)
         assert lib.mpcx_probe_sincos(x.ctypes.data, 4, x.ctypes.data, x.ctypes.data, 0) == -2
+
+
+def test_workspace_sizes(monkeypatch):
+    """mpcx_workspace_bytes: at least one wavefront's share, grows with the spread of the batch,
+    stays under the target (default 64 GiB, MPCX_WORKSPACE_GIB overrides), no device needed."""
+    lib = _lib.load_library()
+    one = lib.mpcx_workspace_bytes(1, 50)
+    assert 1_000_000 < one < 20_000_000
+    assert lib.mpcx_workspace_bytes(0, 50) == 0 and lib.mpcx_workspace_bytes(10, 0) == 0
+    sizes = [lib.mpcx_workspace_bytes(B, 50) for B in (1, 2, 100, 1024, 5000, 10**6, 10**8)]
+    assert sizes[:4] == sorted(sizes[:4]) and max(sizes) == sizes[3] == sizes[-1]    # 1024 wavefronts at most
+    assert sizes[-1] < 1024 * one + 4096
+    big = lib.mpcx_workspace_bytes(3520, 800)
+    assert big <= (64 << 30) + 4096
+    monkeypatch.setenv("MPCX_WORKSPACE_GIB", "4")
+    assert lib.mpcx_workspace_bytes(3520, 800) <= (4 << 30) + 4096
+    assert lib.mpcx_workspace_bytes(1, 50) == one
