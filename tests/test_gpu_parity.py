@@ -204,3 +204,18 @@ def test_device_initial_guess_is_the_host_loop():
         got = _lib.initial_guess_on_device(packed.pdata, np.full(B, width), packed.N)
         assert got.shape == packed.xguess.shape
         assert np.array_equal(got, packed.xguess)
+
+
+def test_obstacle_batch_all_scheduling_paths(oracle, monkeypatch):
+    """2500 problems with one or two obstacles, 64 per wavefront with refill: the one-lane-per-
+    problem sweeps for the young problems, ageing into per-problem regions, the end-of-batch move,
+    all in the kernel variants with obstacle rows, against the oracle."""
+    egos, sim = cases.obstacle_problems(2500, 5.0, seed=9)
+    packed = pack_problems(egos, sim)
+    ref = oracle.solve_packed(packed)
+    assert (ref["status"] == 0).sum() > 50 and ref["qp_iter"].max() > 100
+    for lanes in ("64", "16"):
+        monkeypatch.setenv("MPCX_LANES", lanes)
+        cases.assert_same_solution(_lib.solve_packed(packed), ref, f"obstacle batch, {lanes} per wavefront")
+    monkeypatch.setenv("MPCX_BOOST", "0,0,0")          # no ageing: everything in the wavefront's ticks
+    cases.assert_same_solution(_lib.solve_packed(packed), ref, "obstacle batch, no ageing")
