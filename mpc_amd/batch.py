@@ -146,12 +146,63 @@ def initial_guess(ego, N, corridor=None):
     return out
 
 
-def initial_guess_batch(start, goal, width, N, a, b1, b2):
-    """Vectorised ``initial_guess`` for problems WITHOUT obstacles.
+def adjust_points_one_obstacle(start, goal, x, y, obstacle):
+    """``adjust_point_for_obstacles`` for many problems with ONE obstacle each.
 
-    start, goal: float64 [B, 5]; width, a, b1, b2: float64 [B].
-    Returns [N+1, 5, B] (the library's layout).  Same operations per element
-    as the scalar loop, so the result is identical to it.
+    start, goal: float64 [B, 5]; x, y: the guess points [B]; obstacle: [B, 4]
+    rows (x, y, radius, margin).  The formulas and their order are those of
+    the scalar routine (reference core_solver.py:360-473); squares are plain
+    products here where the scalar code calls pow(), so single results can
+    differ from it in the last bit.
+    """
+    sx, sy, gx, gy = start[:, 0], start[:, 1], goal[:, 0], goal[:, 1]
+    ox, oy = obstacle[:, 0], obstacle[:, 1]
+    total_radius = obstacle[:, 2] + obstacle[:, 3] + 0.05
+    pdx = gx - sx
+    pdy = gy - sy
+    plen = np.sqrt(pdx * pdx + pdy * pdy)
+    degenerate = plen < 1e-6
+    safe = np.where(degenerate, 1.0, plen)
+    pdx = pdx / safe
+    pdy = pdy / safe
+    ndx = -pdy
+    ndy = pdx
+    projection = (ox - sx) * pdx + (oy - sy) * pdy
+    cx = sx + projection * pdx
+    cy = sy + projection * pdy
+    dist_to_path = np.sqrt((cx - ox) * (cx - ox) + (cy - oy) * (cy - oy))
+    on_path = (dist_to_path < total_radius) & (0 <= projection) & (projection <= plen)
+    point_side = (x - sx) * ndx + (y - sy) * ndy
+    shift_direction = np.where(on_path & (point_side < 0), -1.0, 1.0)
+    path_shift = np.where(on_path, total_radius - dist_to_path, 0.0)
+    shifted = path_shift > 0
+    amount = path_shift + 0.1
+    ssx = sx + shift_direction * ndx * amount
+    ssy = sy + shift_direction * ndy * amount
+    proj = (x - ssx) * pdx + (y - ssy) * pdy
+    proj = np.maximum(0.0, np.minimum(proj, plen))
+    x_shift = ssx + proj * pdx
+    y_shift = ssy + proj * pdy
+    # not shifted: a point inside the obstacle is pushed out radially
+    dx = x - ox
+    dy = y - oy
+    inside = np.sqrt(dx * dx + dy * dy) < total_radius
+    angle = np.arctan2(dy, dx)
+    x_push = np.where(inside, ox + total_radius * np.cos(angle), x)
+    y_push = np.where(inside, oy + total_radius * np.sin(angle), y)
+    x_out = np.where(shifted, x_shift, x_push)
+    y_out = np.where(shifted, y_shift, y_push)
+    return np.where(degenerate, x, x_out), np.where(degenerate, y, y_out)
+
+
+def initial_guess_batch(start, goal, width, N, a, b1, b2, obstacle=None):
+    """Vectorised ``initial_guess``.
+
+    start, goal: float64 [B, 5]; width, a, b1, b2: float64 [B]; obstacle: None,
+    or [B, 4] rows (x, y, radius, margin), one obstacle per problem.
+    Returns [N+1, 5, B] (the library's layout).  Without obstacles these are
+    the same operations per element as the scalar loop, so the result is
+    identical to it; with one see ``adjust_points_one_obstacle``.
     """
     B = start.shape[0]
     out = np.empty((N + 1, NX, B), dtype=np.float64)
@@ -162,6 +213,8 @@ def initial_guess_batch(start, goal, width, N, a, b1, b2):
         y = start[:, 1] + t * (goal[:, 1] - start[:, 1])
         yc = -(a * x + b1 / 2 + a * x + b2 / 2) / 2
         y = np.minimum(np.maximum(y, yc - half), yc + half)
+        if obstacle is not None:
+            x, y = adjust_points_one_obstacle(start, goal, x, y, obstacle)
         out[i, 0] = x
         out[i, 1] = y
         out[i, 2] = start[:, 2] + t * (goal[:, 2] - start[:, 2])
@@ -250,9 +303,10 @@ def normalize_angle_array(angle):
 def pack_arrays(start, goal, duration, dt=0.1, corridor_width=15.0, L=2.7,
                 velocity=(-3.0, 3.0), acceleration=(-2.0, 2.0), steering=(-0.5, 0.5),
                 steering_rate=(-0.4, 0.4), weights=(100.0, 100.0, 0.0, 0.0, 0.0, 0.0, 0.0),
-                terminal_weights=(100.0, 100.0, 100.0, 10.0, 10.0)):
-    """Vectorised packing of obstacle-free problems that differ only in start
-    and goal state (the synthetic benchmark batch, the grid sweep).
+                terminal_weights=(100.0, 100.0, 100.0, 10.0, 10.0), obstacle=None):
+    """Vectorised packing of problems that differ only in start and goal state
+    (the synthetic benchmark batch, the grid sweep) and, optionally, in the one
+    obstacle each has (obstacle: [B, 4] rows x, y, radius, margin).
 
     start, goal: [B, 5]; headings are wrapped exactly as the EgoConfig setters
     wrap them.  Every other EgoConfig field takes the given common value
@@ -291,5 +345,12 @@ def pack_arrays(start, goal, duration, dt=0.1, corridor_width=15.0, L=2.7,
     pdata[F_H] = duration / N
     pdata[F_LH] = H_LOWER
     pdata[F_UH] = H_UPPER
-    xguess = initial_guess_batch(start, goal, width, N, a, b1, b2)
-    return PackedBatch(B, N, pdata, np.zeros(B, dtype=np.int32), xguess, float(duration))
+    n_obs = np.zeros(B, dtype=np.int32)
+    if obstacle is not None:
+        obstacle = np.asarray(obstacle, dtype=np.float64)
+        pdata[F_OBS + 0] = obstacle[:, 0]
+        pdata[F_OBS + 1] = obstacle[:, 1]
+        pdata[F_OBS + 2] = (obstacle[:, 2] + obstacle[:, 3])**2
+        n_obs[:] = 1
+    xguess = initial_guess_batch(start, goal, width, N, a, b1, b2, obstacle)
+    return PackedBatch(B, N, pdata, n_obs, xguess, float(duration))

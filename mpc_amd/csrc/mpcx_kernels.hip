@@ -1550,6 +1550,48 @@ __device__ __attribute__((noinline)) double sweep_F(Lane L, PC<NH> pc, const mpc
     return a.alpha[0];
 }
 
+// Diagnostic build only (-DMPCX_STAMPS): per-wavefront cycle sums of each phase
+// of the tick loop, read back by mpcx_debug_read_stamps().  No stamp code is
+// compiled into the shipped library.
+#ifdef MPCX_STAMPS
+#define N_STAMP 64
+__device__ unsigned long long g_stamps[2048][N_STAMP];
+#define STAMP_DECL() unsigned long long st_t0 = 0
+#define STAMP_BEGIN() st_t0 = __builtin_amdgcn_s_memtime()
+#define STAMP(slot, pred)                                                              \
+    do {                                                                               \
+        unsigned long long st_t1 = __builtin_amdgcn_s_memtime();                       \
+        unsigned long long st_n = __popcll(__ballot(pred));                            \
+        if (threadIdx.x == 0) {                                                        \
+            g_stamps[blockIdx.x][2 * (slot)] += st_t1 - st_t0;                         \
+            g_stamps[blockIdx.x][2 * (slot) + 1] += st_n;                              \
+        }                                                                              \
+        st_t0 = __builtin_amdgcn_s_memtime();                                          \
+    } while (0)
+// wall-clock marks (100 MHz counter): the slot keeps the time of the first call
+#define MARK(slot)                                                                     \
+    do {                                                                               \
+        if (g_stamps[blockIdx.x][2 * (slot)] == 0) g_stamps[blockIdx.x][2 * (slot)] = wall_clock64(); \
+    } while (0)
+#define MARK_LAST(slot) do { g_stamps[blockIdx.x][2 * (slot)] = wall_clock64(); } while (0)
+// cycles of a part of a non-inlined function (slots 16..19)
+#define SUB_BEGIN() unsigned long long sub_t0 = __builtin_amdgcn_s_memtime()
+#define SUB_END(slot)                                                                  \
+    do {                                                                               \
+        unsigned long long sub_t1 = __builtin_amdgcn_s_memtime();                      \
+        if (threadIdx.x == 0) g_stamps[blockIdx.x][2 * (slot)] += sub_t1 - sub_t0;     \
+        sub_t0 = __builtin_amdgcn_s_memtime();                                         \
+    } while (0)
+#else
+#define MARK(slot) ((void)0)
+#define MARK_LAST(slot) ((void)0)
+#define STAMP_DECL() ((void)0)
+#define STAMP_BEGIN() ((void)0)
+#define STAMP(slot, pred) ((void)0)
+#define SUB_BEGIN() ((void)0)
+#define SUB_END(slot) ((void)0)
+#endif
+
 // ---------------------------------------------------------------------------
 // single-problem mode.  When a wavefront has only a few problems left (the end of
 // a batch, or a call with a handful of problems) one lane per problem leaves the
@@ -1672,6 +1714,7 @@ __device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const
     // lowest stage of the block above
     const KR kr = {kj == 0, kj == N};
     B0In<NH> ld = {};
+    SUB_BEGIN();
     if (kj <= N) stage_B0_head<NH, ANY>(S, 0, sp, ld, kr);
     double vxn[NX], qpin[NX];
 #pragma unroll
@@ -1687,6 +1730,7 @@ __device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const
     }
     B0Out t = {};
     if (kj <= N) stage_B0_tail<NH, ANY>(S, o, pc, 0, sp, ld, vxn, qpin, t, kr);
+    SUB_END(16);
     // reductions over the stages of the block, downwards
     const int kend = (N - k0 < 63) ? N - k0 : 63;
     lds_order();
@@ -1697,6 +1741,7 @@ __device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const
         nd = dmax(nd, bcast(t.nd, kk)); nm = dmax(nm, bcast(t.nm, kk));
         sum = sum + bcast(t.ssum, kk);
     }
+    SUB_END(17);
     // Riccati recursion down the lanes; cP, cp: P and p of the lowest stage of the block above
     double cP[15], cp[NX];
 #pragma unroll
@@ -1724,6 +1769,7 @@ __device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const
         for (int i = 0; i < NX; ++i) pi[i] = from_lane_above(po[i], cp[i]);
         if (kj < N) stage_B0_ric<MID>(S, t, Pi, pi, Po, po, ro);
     }
+    SUB_END(18);
     if (j == 0) {
 #pragma unroll
         for (int i = 0; i < 15; ++i) carry[CY_P + i] = Po[i];
@@ -1732,6 +1778,7 @@ __device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const
     }
     lds_order();
     if (kj <= N) store_ric<NH>(S, 0, kj < N, kj > 0, ro, Po);
+    SUB_END(19);
 }
 
 template <int NH>
@@ -1765,7 +1812,9 @@ __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_
         const Lane S = stage_lane(C, (unsigned)kj);
         BsOut t = {};
         const KR kr = {kj == 0, kj == N};
+        SUB_BEGIN();
         if (kj <= N) stage_Bs_rows<NH, ANY>(S, o, pc, 0, sigma_mu, t, kr);
+        SUB_END(24);
         double o1[NX], o2[NX], kvo[2][NU] = {{0.0, 0.0}, {0.0, 0.0}};
 #pragma unroll
         for (int i = 0; i < NX; ++i) { o1[i] = 0.0; o2[i] = 0.0; }
@@ -1786,6 +1835,7 @@ __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) { c1[i] = bcast(o1[i], 0); c2[i] = bcast(o2[i], 0); }
+        SUB_END(25);
         if (kj <= N) store_rec<NH>(S, 0, kj < N, kj > 0, kvo, o1, o2);
     }
 }
@@ -1808,6 +1858,7 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
         // everything the sweep reads of this lane's stage, in one round trip
         const KR kr = {kj == 0, kj == N};
         FIn<NH, NS> ld = {};
+        SUB_BEGIN();
         if (kj <= N) stage_F_load<NH, ANY, NS>(S, 0, ld, kr);
         // the recursion up the lanes: dxi = state step entering this lane's stage, dxo = leaving it
         const int kend = (N - k0 < 63) ? N - k0 : 63;
@@ -1831,6 +1882,7 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
         for (int q = 0; q < NS; ++q)
 #pragma unroll
             for (int i = 0; i < NX; ++i) cdx[q][i] = bcast(dxo[q][i], 63);
+        SUB_END(26);
         FAcc a = {{1.0, 1.0}, 0.0, 0.0};
         if (kj <= N) stage_F_compute<NH, ANY, NS>(S, o, pc, 0, sigma_mu, ld, dxi, a, kr);
         for (int kk = 0; kk <= kend; ++kk) {
@@ -1841,6 +1893,7 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
             }
             if (NS == 1) { s1 = s1 + bcast(a.s1, kk); s2 = s2 + bcast(a.s2, kk); }
         }
+        SUB_END(27);
     }
     if (NS == 1) { ret[0 * 64] = s1; ret[1 * 64] = s2; }
     else ret[0 * 64] = alpha[1];
@@ -1905,37 +1958,6 @@ __device__ __attribute__((noinline)) void coop_L(Lane C, PC<NH> pc, const mpcx_o
 // need very different numbers of iterations.  Which lane solves which problem
 // does not influence any result.
 // ---------------------------------------------------------------------------
-// Diagnostic build only (-DMPCX_STAMPS): per-wavefront cycle sums of each phase
-// of the tick loop, read back by mpcx_debug_read_stamps().  No stamp code is
-// compiled into the shipped library.
-#ifdef MPCX_STAMPS
-#define N_STAMP 48
-__device__ unsigned long long g_stamps[2048][N_STAMP];
-#define STAMP_DECL() unsigned long long st_t0 = 0
-#define STAMP_BEGIN() st_t0 = __builtin_amdgcn_s_memtime()
-#define STAMP(slot, pred)                                                              \
-    do {                                                                               \
-        unsigned long long st_t1 = __builtin_amdgcn_s_memtime();                       \
-        unsigned long long st_n = __popcll(__ballot(pred));                            \
-        if (threadIdx.x == 0) {                                                        \
-            g_stamps[blockIdx.x][2 * (slot)] += st_t1 - st_t0;                         \
-            g_stamps[blockIdx.x][2 * (slot) + 1] += st_n;                              \
-        }                                                                              \
-        st_t0 = __builtin_amdgcn_s_memtime();                                          \
-    } while (0)
-// wall-clock marks (100 MHz counter): the slot keeps the time of the first call
-#define MARK(slot)                                                                     \
-    do {                                                                               \
-        if (g_stamps[blockIdx.x][2 * (slot)] == 0) g_stamps[blockIdx.x][2 * (slot)] = wall_clock64(); \
-    } while (0)
-#define MARK_LAST(slot) do { g_stamps[blockIdx.x][2 * (slot)] = wall_clock64(); } while (0)
-#else
-#define MARK(slot) ((void)0)
-#define MARK_LAST(slot) ((void)0)
-#define STAMP_DECL() ((void)0)
-#define STAMP_BEGIN() ((void)0)
-#define STAMP(slot, pred) ((void)0)
-#endif
 
 enum LaneState {
     LS_FETCH = 0,   // needs a problem
@@ -2024,7 +2046,9 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     };
     // one interior-point iteration of the problem of lane p, the wavefront with a lane per stage
     auto single_qp = [&](int p) {
+        SUB_BEGIN();
         coop_sync();
+        SUB_END(28);
         Lane C;
         PC<NH> pcc;
         problem_of_lane<NH>(L, pc, (ldouble *)pc_lds, p, C, pcc);
@@ -2036,7 +2060,9 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         const int mt = __builtin_amdgcn_readlane(m_total, p);
         int qit = __builtin_amdgcn_readlane(qp_it, p);
         int n_state = LS_QP, n_status = -1, add_total = 0, add_sqp = 0;
+        SUB_END(29);
         coop_B0<NH>(C, pcc, op, s, mt, ret);
+        SUB_END(30);
         STAMP(12, true);
         const double Rg = uniform(ret[0 * 64]), Rb = uniform(ret[1 * 64]), Rd = uniform(ret[2 * 64]),
                      Rm = uniform(ret[3 * 64]), mu = uniform(ret[4 * 64]);

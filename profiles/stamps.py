@@ -33,7 +33,7 @@ if ONLY >= 0:
 t0 = time.time()
 out = _lib.solve_packed(packed)
 dt = time.time() - t0
-NS = 48
+NS = 64
 buf = np.zeros((2048, NS), dtype=np.uint64)
 lib.mpcx_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.mpcx_debug_read_stamps(buf.ctypes.data, 1) == 0
@@ -47,11 +47,24 @@ print(f"B={B} wall {dt:.2f}s (incl. transfers); waves with work: {used.sum()}")
 mark_slots = [20, 21, 22, 23]
 marks_raw = cyc[:, mark_slots].copy()
 cyc[:, mark_slots] = 0
+# parts of the single-problem sweeps (already contained in slots 12..15)
+sub_slots = {16: "    B0 loads + rows", 17: "    B0 reductions", 18: "    B0 Riccati pipeline", 19: "    B0 stores",
+             24: "    Bs loads + rows", 25: "    Bs pipeline + stores", 26: "    F loads + pipeline",
+             27: "    F rows + reductions", 28: "    fence before B0", 29: "    problem parameters",
+             30: "    B0 call"}
+sub_raw = {k: cyc[used, k].sum() for k in sub_slots}
+cyc[:, list(sub_slots)] = 0
 tot = cyc[used].sum()
 ticks = None
 for i, n in enumerate(names):
     c = cyc[used, i].sum()
     print(f"{n:22s} share {100 * c / tot:5.1f}%   cycles {c:.4g}  lanes-sum {cnt[used, i].sum():.3g}")
+for k, n in sub_slots.items():
+    print(f"{n:26s} share {100 * sub_raw[k] / tot:5.1f}%   cycles {sub_raw[k]:.4g}")
+for i in (12, 13, 14, 15):
+    calls = cnt[used, i].sum() / 64
+    if calls:
+        print(f"{names[i]:22s} calls {calls:.4g}  cycles per call {cyc[used, i].sum() / calls:.0f}")
 print("cycles per wave (mean) %.3g" % cyc[used].sum(1).mean())
 w = cyc[used].sum(1)
 print("cycles per wave: min %.3g median %.3g p90 %.3g max %.3g" % (w.min(), np.median(w), np.percentile(w, 90), w.max()))

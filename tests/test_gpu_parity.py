@@ -54,6 +54,18 @@ def test_synthetic_batch_matches_oracle(oracle, B):
     assert (ref["status"] == 0).any() or B < 20
 
 
+@pytest.mark.parametrize("B", [64, 3000])
+def test_synthetic_obstacle_batch_matches_oracle(oracle, B):
+    """The benchmark's second workload: one obstacle per problem beside the middle of the path."""
+    packed = synthetic_batch(B, obstacle=True)
+    assert (packed.n_obs == 1).all()
+    gpu = _lib.solve_packed(packed)
+    ref = oracle.solve_packed(packed)
+    cases.assert_same_solution(gpu, ref, f"synthetic with obstacle B={B}")
+    if B >= 1000:
+        assert (ref["status"] == 0).any()
+
+
 def test_scenarios_match_oracle(oracle):
     names = list(cases.SCENARIOS)
     egos, sims = zip(*(cases.make_scenario(n) for n in names))

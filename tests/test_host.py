@@ -95,6 +95,33 @@ def test_vectorised_packing_equals_scalar():
     assert np.array_equal(packed_v.n_obs, packed_s.n_obs)
 
 
+def test_vectorised_obstacle_guess_equals_scalar():
+    """One obstacle per problem: the vectorised guess against the scalar loop through EgoConfig.
+    The vectorised routine squares by multiplication where the scalar code calls pow(), so the
+    bound is 1e-12 rather than equality; table fields must be equal."""
+    B = 200
+    start, goal, obs = random_start_goal(B, seed=5, with_obstacle=True)
+    # both branches of the adjustment occur: line shifted (offset < 1.55) and not
+    off = np.hypot(obs[:, 0] - (start[:, 0] + goal[:, 0]) / 2, obs[:, 1] - (start[:, 1] + goal[:, 1]) / 2)
+    assert (off < 1.55).any() and (off > 1.55).any() and (off >= 0.5 - 1e-9).all() and (off <= 2 + 1e-9).all()
+    egos = []
+    for b in range(B):
+        e = EgoConfig()
+        e.state_start = list(start[b])
+        e.state_final = list(goal[b])
+        e.obstacles = [list(obs[b])]
+        egos.append(e)
+    sim = SimConfig()
+    sim.duration = 5.0
+    ref = bt.pack_problems(egos, sim)
+    vec = synthetic_batch(B, seed=5, obstacle=True)
+    assert np.array_equal(ref.pdata, vec.pdata) and np.array_equal(ref.n_obs, vec.n_obs)
+    assert np.abs(ref.xguess - vec.xguess).max() <= 1e-12
+    # the starts and goals are those of the obstacle-free batch of the same seed
+    free = synthetic_batch(B, seed=5)
+    assert np.array_equal(free.pdata[bt.F_X0:bt.F_X0 + 5], vec.pdata[bt.F_X0:bt.F_X0 + 5])
+
+
 def test_pack_fields():
     ego, sim = cases.make_scenario("path_finder")
     p = bt.pack_problems([ego], sim)
