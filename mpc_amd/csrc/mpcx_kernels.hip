@@ -1679,6 +1679,59 @@ DEV double from_lane_below(double v, double edge)
     return __hiloint2double(hi, lo);      // wave_shr:1
 }
 
+// The same with zero as the edge value (all a sweep over a single block of stages needs): the
+// move then writes every lane, which saves the copy of `edge` into the destination beforehand.
+template <bool ZERO>
+DEV double lane_above(double v, double edge)
+{
+    if (!ZERO) return from_lane_above(v, edge);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <bool ZERO>
+DEV double lane_below(double v, double edge)
+{
+    if (!ZERO) return from_lane_below(v, edge);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// The maxima and minima over the stages do not depend on the order (the per-stage values are
+// never NaN: each starts from the identity and is updated by a comparison that a NaN fails), so
+// they are reduced by a DPP tree; lanes without a source take the identity.  The sums stay chains.
+template <int CTRL>
+DEV double dpp_take(double v, double idv)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(idv), __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(idv), __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+DEV double dmin(double a, double b) { return (b < a) ? b : a; }
+// v >= 0 in every lane; the largest, in all lanes
+DEV double wave_max(double v)
+{
+    v = dmax(v, dpp_take<0x111>(v, 0.0));      // row_shr:1, 2, 4, 8: lane 15 of a row has the row's
+    v = dmax(v, dpp_take<0x112>(v, 0.0));
+    v = dmax(v, dpp_take<0x114>(v, 0.0));
+    v = dmax(v, dpp_take<0x118>(v, 0.0));
+    v = dmax(v, dpp_take<0x142>(v, 0.0));      // row_bcast:15, then :31: lane 63 has the wavefront's
+    v = dmax(v, dpp_take<0x143>(v, 0.0));
+    return bcast(v, 63);
+}
+// v <= 1 in every lane; the smallest, in all lanes
+DEV double wave_min(double v)
+{
+    v = dmin(v, dpp_take<0x111>(v, 1.0));
+    v = dmin(v, dpp_take<0x112>(v, 1.0));
+    v = dmin(v, dpp_take<0x114>(v, 1.0));
+    v = dmin(v, dpp_take<0x118>(v, 1.0));
+    v = dmin(v, dpp_take<0x142>(v, 1.0));
+    v = dmin(v, dpp_take<0x143>(v, 1.0));
+    return bcast(v, 63);
+}
+
 // The recursions run as a pipeline over the lanes.  Every lane keeps the operands of its own
 // stage and, each step, recomputes its stage from what the neighbouring lane produced in the
 // step before.  The lane at the start of the chain has its true input from the first step
@@ -1698,7 +1751,7 @@ DEV void lds_order()
 
 // one block of 64 consecutive stages (k0 .. k0+63) of sweep B0; what the block above handed
 // down, and the running reductions, are read from and left in the carry words
-template <int NH>
+template <int NH, bool ONE>
 __device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const mpcx_opts *op, bool sp_have, int sp_mode,
                                                         double sp_sigma_mu, double sp_alpha, int k0, ldouble *ret)
 {
@@ -1719,8 +1772,8 @@ __device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const
     double vxn[NX], qpin[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        vxn[i] = from_lane_above(ld.v[NU + i], carry[CY_VX + i]);
-        qpin[i] = from_lane_above(ld.qpi[i], carry[CY_QPI + i]);
+        vxn[i] = lane_above<ONE>(ld.v[NU + i], carry[CY_VX + i]);
+        qpin[i] = lane_above<ONE>(ld.qpi[i], carry[CY_QPI + i]);
     }
     lds_order();
 #pragma unroll
@@ -1736,10 +1789,17 @@ __device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const
     lds_order();
     double ng = carry[CY_NORM + 0], nb = carry[CY_NORM + 1], nd = carry[CY_NORM + 2], nm = carry[CY_NORM + 3],
            sum = carry[CY_NORM + 4];
-    for (int kk = kend; kk >= 0; --kk) {
-        ng = dmax(ng, bcast(t.ng, kk)); nb = dmax(nb, bcast(t.nb, kk));
-        nd = dmax(nd, bcast(t.nd, kk)); nm = dmax(nm, bcast(t.nm, kk));
-        sum = sum + bcast(t.ssum, kk);
+    ng = dmax(ng, wave_max(t.ng)); nb = dmax(nb, wave_max(t.nb));       // (zero in lanes without a stage)
+    nd = dmax(nd, wave_max(t.nd)); nm = dmax(nm, wave_max(t.nm));
+    {
+        // the sum is a chain from stage kend down to the block's first: the same pipeline as
+        // the recursions (lanes above kend keep handing down the value the chain starts from)
+        const double start = sum;
+        for (int s = 0; s <= kend; ++s) {
+            const double in = lane_above<ONE>(sum, start);
+            sum = (j <= kend) ? in + t.ssum : in;
+        }
+        sum = bcast(sum, 0);
     }
     SUB_END(17);
     // Riccati recursion down the lanes; cP, cp: P and p of the lowest stage of the block above
@@ -1764,9 +1824,9 @@ __device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const
     for (int s = 0; s < steps; ++s) {
         double Pi[15], pi[NX];
 #pragma unroll
-        for (int i = 0; i < 15; ++i) Pi[i] = from_lane_above(Po[i], cP[i]);
+        for (int i = 0; i < 15; ++i) Pi[i] = lane_above<ONE>(Po[i], cP[i]);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) pi[i] = from_lane_above(po[i], cp[i]);
+        for (int i = 0; i < NX; ++i) pi[i] = lane_above<ONE>(po[i], cp[i]);
         if (kj < N) stage_B0_ric<MID>(S, t, Pi, pi, Po, po, ro);
     }
     SUB_END(18);
@@ -1789,8 +1849,12 @@ DEV void coop_B0(const Lane &C, const PC<NH> &pc, const mpcx_opts *op, const Ste
     if (threadIdx.x < CY_N) carry[threadIdx.x] = 0.0;
     lds_order();
     // blocks of 64 consecutive stages, the last block first
-    for (int k0 = (N / 64) * 64; k0 >= 0; k0 -= 64)
-        coop_B0_block<NH>(C, pc, op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, k0, ret);
+    if (N < 64) {      // a single block: everything handed down from above is zero
+        coop_B0_block<NH, true>(C, pc, op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, 0, ret);
+    } else {
+        for (int k0 = (N / 64) * 64; k0 >= 0; k0 -= 64)
+            coop_B0_block<NH, false>(C, pc, op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, k0, ret);
+    }
     lds_order();
     const double ng = carry[CY_NORM + 0], nb = carry[CY_NORM + 1], nd = carry[CY_NORM + 2], nm = carry[CY_NORM + 3],
                  sum = carry[CY_NORM + 4];
@@ -1824,8 +1888,8 @@ __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_
             double i1[NX], i2[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                i1[i] = from_lane_above(o1[i], c1[i]);
-                i2[i] = from_lane_above(o2[i], c2[i]);
+                i1[i] = lane_above<ONE>(o1[i], c1[i]);
+                i2[i] = lane_above<ONE>(o2[i], c2[i]);
             }
             if (kj < N) {
                 stage_Bs_rec<MID>(S, t, i1, i2, kvo);
@@ -1871,7 +1935,7 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) dxi[q][i] = from_lane_below(dxo[q][i], cdx[q][i]);
+                for (int i = 0; i < NX; ++i) dxi[q][i] = lane_below<ONE>(dxo[q][i], cdx[q][i]);
                 if (kj < N) {
                     double du[NU];
                     F_rec(C, ld.ab, ld.kg, ld.kv[q], ld.rb, dxi[q], du, dxo[q]);
@@ -1885,13 +1949,16 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
         SUB_END(26);
         FAcc a = {{1.0, 1.0}, 0.0, 0.0};
         if (kj <= N) stage_F_compute<NH, ANY, NS>(S, o, pc, 0, sigma_mu, ld, dxi, a, kr);
-        for (int kk = 0; kk <= kend; ++kk) {
 #pragma unroll
-            for (int q = 0; q < NS; ++q) {
-                const double ak = bcast(a.alpha[q], kk);
-                alpha[q] = (ak < alpha[q]) ? ak : alpha[q];
+        for (int q = 0; q < NS; ++q) alpha[q] = dmin(alpha[q], wave_min(a.alpha[q]));      // (1 in lanes without a stage)
+        if (NS == 1) {      // chains from the block's first stage up to stage kend
+            const double st1 = s1, st2 = s2;
+            for (int s = 0; s <= kend; ++s) {
+                const double i1 = lane_below<ONE>(s1, st1), i2 = lane_below<ONE>(s2, st2);
+                s1 = (j <= kend) ? i1 + a.s1 : i1;
+                s2 = (j <= kend) ? i2 + a.s2 : i2;
             }
-            if (NS == 1) { s1 = s1 + bcast(a.s1, kk); s2 = s2 + bcast(a.s2, kk); }
+            s1 = bcast(s1, kend); s2 = bcast(s2, kend);
         }
         SUB_END(27);
     }
@@ -1940,10 +2007,16 @@ __device__ __attribute__((noinline)) void coop_L(Lane C, PC<NH> pc, const mpcx_o
         const KR kr = {kj == 0, kj == N};
         if (kj <= N) stage_L<NH, ANY, true>(S, o, pc, 0, first, xk, pik, a, kr, nxt);
         const int kend = (N - k0 < 63) ? N - k0 : 63;
-        for (int kk = 0; kk <= kend; ++kk) {
-            tot.rs = dmax(tot.rs, bcast(a.rs, kk)); tot.re = dmax(tot.re, bcast(a.re, kk));
-            tot.ri = dmax(tot.ri, bcast(a.ri, kk)); tot.rc = dmax(tot.rc, bcast(a.rc, kk));
-            tot.cost = tot.cost + bcast(a.cost, kk);
+        tot.rs = dmax(tot.rs, wave_max(a.rs)); tot.re = dmax(tot.re, wave_max(a.re));
+        tot.ri = dmax(tot.ri, wave_max(a.ri)); tot.rc = dmax(tot.rc, wave_max(a.rc));
+        {
+            const double start = tot.cost;
+            double c = start;
+            for (int s = 0; s <= kend; ++s) {
+                const double in = lane_below<ONE>(c, start);
+                c = (j <= kend) ? in + a.cost : in;
+            }
+            tot.cost = bcast(c, kend);
         }
     }
     ret[0 * 64] = tot.rs; ret[1 * 64] = tot.re; ret[2 * 64] = tot.ri; ret[3 * 64] = tot.rc;
