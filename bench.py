@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--seed", type=int, default=None, help="batch seed of rank 0 (default: the headline seed)")
     ap.add_argument("--obstacle", action="store_true",
                     help="second workload: one obstacle (r=1, margin 0.5) beside the middle of every path")
+    ap.add_argument("--lib", default=None, help="another build of the library (diagnostic builds)")
     ap.add_argument("--cpu-sample", type=int, default=262144, help="problems timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
@@ -52,7 +53,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    lib = _lib.load_library()
+    lib = _lib.load_library(args.lib)
     opts = _lib.default_opts(lib)
     opts.max_obs = 1 if args.obstacle else 0
 

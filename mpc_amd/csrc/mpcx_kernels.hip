@@ -144,11 +144,33 @@ DEV gdouble *wsp(const Lane &L, int k, int f, unsigned extra)
     gchar *base = (gchar *)(L.wave + ((size_t)k * L.F + f) * 64);
     return (gdouble *)(base + (L.lane + extra));
 }
-DEV double ldw(const Lane &L, int k, int f) { return *wsp(L, k, f, 0u); }
-DEV void stw(const Lane &L, int k, int f, double v) { *wsp(L, k, f, 0u) = v; }
+// Stage code is instantiated per kind of stage: FIRST / MID / LAST in one-lane-per-problem
+// mode, where the kind is known at compile time, and ANY in single-problem mode, where each
+// lane has a stage of its own and the kind is a run-time value.
+enum { FIRST = 0, MID = 1, LAST = 2, ANY = 3 };
+// Workspace accesses.  In one-lane-per-problem mode a wavefront streams through megabytes
+// between two uses of the same word, so those accesses carry the non-temporal hint and do not
+// push the single-problem regions (reused every ~100 us) out of the L2.
+#ifndef MPCX_STREAM_HINT
+#define MPCX_STREAM_HINT 1
+#endif
+template <int KIND> DEV double ldw(const Lane &L, int k, int f)
+{
+    if (MPCX_STREAM_HINT && KIND != ANY) return __builtin_nontemporal_load(wsp(L, k, f, 0u));
+    return *wsp(L, k, f, 0u);
+}
+template <int KIND> DEV void stw(const Lane &L, int k, int f, double v)
+{
+    if (MPCX_STREAM_HINT && KIND != ANY) __builtin_nontemporal_store(v, wsp(L, k, f, 0u));
+    else *wsp(L, k, f, 0u) = v;
+}
 DEV double ldp(const Lane &L, int f) { return (L.pdata + (size_t)f * L.B)[L.b]; }
 // field f + df where df differs from lane to lane
-DEV double ldw_lane(const Lane &L, int k, int f, int df) { return *wsp(L, k, f, 512u * (unsigned)df); }
+template <int KIND> DEV double ldw_lane(const Lane &L, int k, int f, int df)
+{
+    if (MPCX_STREAM_HINT && KIND != ANY) return __builtin_nontemporal_load(wsp(L, k, f, 512u * (unsigned)df));
+    return *wsp(L, k, f, 512u * (unsigned)df);
+}
 
 DEV double dabs(double a) { return (a < 0.0) ? -a : a; }
 DEV double dmax(double a, double b) { return (b > a) ? b : a; }
@@ -316,26 +338,26 @@ DEV void rk4_sens(const Lane &L, const double *x, const double *u, double *xn, A
     ab.b21 = h6 * (A.k26 + K.k26);
 }
 
-template <int NH>
+template <int NH, int KIND>
 DEV void load_ab(const Lane &L, int k, AB &ab)
 {
     typedef Map<NH> M;
-    ab.a02 = ldw(L, k, M::AB + 0);  ab.a03 = ldw(L, k, M::AB + 1);  ab.a04 = ldw(L, k, M::AB + 2);
-    ab.a12 = ldw(L, k, M::AB + 3);  ab.a13 = ldw(L, k, M::AB + 4);  ab.a14 = ldw(L, k, M::AB + 5);
-    ab.a23 = ldw(L, k, M::AB + 6);  ab.a24 = ldw(L, k, M::AB + 7);
-    ab.b00 = ldw(L, k, M::AB + 8);  ab.b10 = ldw(L, k, M::AB + 9);  ab.b20 = ldw(L, k, M::AB + 10);
-    ab.b01 = ldw(L, k, M::AB + 11); ab.b11 = ldw(L, k, M::AB + 12); ab.b21 = ldw(L, k, M::AB + 13);
+    ab.a02 = ldw<KIND>(L, k, M::AB + 0);  ab.a03 = ldw<KIND>(L, k, M::AB + 1);  ab.a04 = ldw<KIND>(L, k, M::AB + 2);
+    ab.a12 = ldw<KIND>(L, k, M::AB + 3);  ab.a13 = ldw<KIND>(L, k, M::AB + 4);  ab.a14 = ldw<KIND>(L, k, M::AB + 5);
+    ab.a23 = ldw<KIND>(L, k, M::AB + 6);  ab.a24 = ldw<KIND>(L, k, M::AB + 7);
+    ab.b00 = ldw<KIND>(L, k, M::AB + 8);  ab.b10 = ldw<KIND>(L, k, M::AB + 9);  ab.b20 = ldw<KIND>(L, k, M::AB + 10);
+    ab.b01 = ldw<KIND>(L, k, M::AB + 11); ab.b11 = ldw<KIND>(L, k, M::AB + 12); ab.b21 = ldw<KIND>(L, k, M::AB + 13);
 }
 
-template <int NH>
+template <int NH, int KIND>
 DEV void store_ab(const Lane &L, int k, const AB &ab)
 {
     typedef Map<NH> M;
-    stw(L, k, M::AB + 0, ab.a02);  stw(L, k, M::AB + 1, ab.a03);  stw(L, k, M::AB + 2, ab.a04);
-    stw(L, k, M::AB + 3, ab.a12);  stw(L, k, M::AB + 4, ab.a13);  stw(L, k, M::AB + 5, ab.a14);
-    stw(L, k, M::AB + 6, ab.a23);  stw(L, k, M::AB + 7, ab.a24);
-    stw(L, k, M::AB + 8, ab.b00);  stw(L, k, M::AB + 9, ab.b10);  stw(L, k, M::AB + 10, ab.b20);
-    stw(L, k, M::AB + 11, ab.b01); stw(L, k, M::AB + 12, ab.b11); stw(L, k, M::AB + 13, ab.b21);
+    stw<KIND>(L, k, M::AB + 0, ab.a02);  stw<KIND>(L, k, M::AB + 1, ab.a03);  stw<KIND>(L, k, M::AB + 2, ab.a04);
+    stw<KIND>(L, k, M::AB + 3, ab.a12);  stw<KIND>(L, k, M::AB + 4, ab.a13);  stw<KIND>(L, k, M::AB + 5, ab.a14);
+    stw<KIND>(L, k, M::AB + 6, ab.a23);  stw<KIND>(L, k, M::AB + 7, ab.a24);
+    stw<KIND>(L, k, M::AB + 8, ab.b00);  stw<KIND>(L, k, M::AB + 9, ab.b10);  stw<KIND>(L, k, M::AB + 10, ab.b20);
+    stw<KIND>(L, k, M::AB + 11, ab.b01); stw<KIND>(L, k, M::AB + 12, ab.b11); stw<KIND>(L, k, M::AB + 13, ab.b21);
 }
 
 // acc[c] += sum_i BA[i][c] * w[i], c = 0..6 ([B A] columns), i ascending
@@ -378,7 +400,7 @@ DEV void mul_AB(const Lane &L, const AB &ab, const double *dx, const double *du,
 // wavefront work on different stages).  The code of a stage is then the code of a middle
 // stage, every row and variable computed, and what the stage does not have is kept out of the
 // results by selects; for the three fixed kinds the same selects fold away at compile time.
-enum { FIRST = 0, MID = 1, LAST = 2, ANY = 3 };
+
 struct KR { bool first, last; };
 
 template <int KIND> DEV constexpr bool row_present(int r)      // can a stage of this kind have row r
@@ -529,10 +551,10 @@ DEV void load_xu(const Lane &L, int k, const KR &kr, double *x, double *u)
 {
     typedef Map<NH> M;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = ldw(L, k, M::X + i);
+    for (int i = 0; i < NX; ++i) x[i] = ldw<KIND>(L, k, M::X + i);
     u[0] = u[1] = 0.0;
     if (KIND != LAST) {
-        const double u0 = ldw(L, k, M::U + 0), u1 = ldw(L, k, M::U + 1);
+        const double u0 = ldw<KIND>(L, k, M::U + 0), u1 = ldw<KIND>(L, k, M::U + 1);
         u[0] = is_last<KIND>(kr) ? 0.0 : u0;
         u[1] = is_last<KIND>(kr) ? 0.0 : u1;
     }
@@ -580,20 +602,20 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
     for (int i = 0; i < NX; ++i) { xn1[i] = 0.0; vxn1[i] = 0.0; pin1[i] = 0.0; }
     if (KIND != LAST) {
 #pragma unroll
-        for (int c = 0; c < NU; ++c) { uk[c] = ldw(L, k, M::U + c); vu[c] = ldw(L, k, M::V + c); }
+        for (int c = 0; c < NU; ++c) { uk[c] = ldw<KIND>(L, k, M::U + c); vu[c] = ldw<KIND>(L, k, M::V + c); }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            xn1[i] = COOP ? nxt[i] : ldw(L, k + 1, M::X + i);
-            vxn1[i] = COOP ? nxt[NX + i] : ldw(L, k + 1, M::V + NU + i);
-            pin1[i] = COOP ? nxt[2 * NX + i] : ldw(L, k + 1, M::QPI + i);
+            xn1[i] = COOP ? nxt[i] : ldw<KIND>(L, k + 1, M::X + i);
+            vxn1[i] = COOP ? nxt[NX + i] : ldw<KIND>(L, k + 1, M::V + NU + i);
+            pin1[i] = COOP ? nxt[2 * NX + i] : ldw<KIND>(L, k + 1, M::QPI + i);
         }
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
         ll[r] = 0.0; lu[r] = 0.0;
         if (!row_present<KIND>(r)) continue;
-        ll[r] = ldw(L, k, M::LAML + r);
-        lu[r] = ldw(L, k, M::LAMU + r);
+        ll[r] = ldw<KIND>(L, k, M::LAML + r);
+        lu[r] = ldw<KIND>(L, k, M::LAMU + r);
     }
     __builtin_amdgcn_sched_barrier(0);
     // SQP step (nothing to add before the first QP; v is uninitialised then)
@@ -603,22 +625,22 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
         for (int c = 0; c < NU; ++c) {
             uk[c] = first ? uk[c] : uk[c] + vu[c];
             uk[c] = is_last<KIND>(kr) ? 0.0 : uk[c];
-            stw(L, k, M::U + c, uk[c]);
+            stw<KIND>(L, k, M::U + c, uk[c]);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn1[i] = first ? xn1[i] : xn1[i] + vxn1[i];
         double xn[NX];
         rk4_sens(L, xk, uk, xn, ab);
-        store_ab<NH>(L, k, ab);
+        store_ab<NH, KIND>(L, k, ab);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             double bv = xn[i] - xn1[i];
-            stw(L, k, M::BV + i, bv);
+            stw<KIND>(L, k, M::BV + i, bv);
             a.re = is_last<KIND>(kr) ? a.re : dmax(a.re, dabs(bv));
         }
     }
 #pragma unroll
-    for (int i = 0; i < NX; ++i) stw(L, k, M::X + i, xk[i]);
+    for (int i = 0; i < NX; ++i) stw<KIND>(L, k, M::X + i, xk[i]);
     // stationarity of the Lagrangian
     double g[NZ], Hd[NZ], gl[NZ];
     cost_terms<NH, KIND>(L, o, pc, kr, xk, uk, g, Hd);
@@ -683,22 +705,22 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
             tl = (tl < thr0) ? thr0 : tl;
             tu = (tu < thr0) ? thr0 : tu;
         }
-        stw(L, k, M::TL + r, tl);
-        stw(L, k, M::TU + r, tu);
-        stw(L, k, M::LAML + r, mu0 / tl);
-        stw(L, k, M::LAMU + r, mu0 / tu);
+        stw<KIND>(L, k, M::TL + r, tl);
+        stw<KIND>(L, k, M::TU + r, tu);
+        stw<KIND>(L, k, M::LAML + r, mu0 / tl);
+        stw<KIND>(L, k, M::LAMU + r, mu0 / tu);
         if (MPCX_STORE_RECIP) {
-            stw(L, k, M::TIL + r, 1.0 / tl);
-            stw(L, k, M::TIU + r, 1.0 / tu);
+            stw<KIND>(L, k, M::TIL + r, 1.0 / tl);
+            stw<KIND>(L, k, M::TIU + r, 1.0 / tu);
         }
     }
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
         if (var_present<KIND>(j)) a.rs = var_on<KIND>(kr, j) ? dmax(a.rs, dabs(gl[j])) : a.rs;
-        stw(L, k, M::V + j, vq[j]);
+        stw<KIND>(L, k, M::V + j, vq[j]);
     }
 #pragma unroll
-    for (int i = 0; i < NX; ++i) stw(L, k, M::QPI + i, 0.0);
+    for (int i = 0; i < NX; ++i) stw<KIND>(L, k, M::QPI + i, 0.0);
     // objective: summed per stage, then over the stages
     double ck = 0.0, cke = 0.0;
     if (KIND != LAST) {
@@ -737,7 +759,7 @@ __device__ __attribute__((noinline)) void sweep_L(Lane L, PC<NH> pc, const mpcx_
     double xk[NX], pik[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        double x0 = ldw(L, 0, M::X + i), v0 = ldw(L, 0, M::V + NU + i);
+        double x0 = ldw<MID>(L, 0, M::X + i), v0 = ldw<MID>(L, 0, M::V + NU + i);
         xk[i] = first ? x0 : x0 + v0;
         pik[i] = 0.0;
     }
@@ -795,26 +817,26 @@ DEV void stage_B0_head(const Lane &L, int k, const Step &sp, B0In<NH> &in, const
     load_xu<NH, KIND>(L, k, kr, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
-        vo[j] = ldw(L, k, M::V + j);
-        dv[j] = ldw_lane(L, k, M::DV + j, sol);
-        dva[j] = ldw(L, k, M::DVA + j);
+        vo[j] = ldw<KIND>(L, k, M::V + j);
+        dv[j] = ldw_lane<KIND>(L, k, M::DV + j, sol);
+        dva[j] = ldw<KIND>(L, k, M::DVA + j);
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        qpi[i] = (KIND != FIRST) ? ldw(L, k, M::QPI + i) : 0.0;
-        dpi[i] = (KIND != FIRST) ? ldw_lane(L, k, M::DPI + i, sol) : 0.0;
+        qpi[i] = (KIND != FIRST) ? ldw<KIND>(L, k, M::QPI + i) : 0.0;
+        dpi[i] = (KIND != FIRST) ? ldw_lane<KIND>(L, k, M::DPI + i, sol) : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
         ll[r] = lu[r] = tl[r] = tu[r] = til_[r] = tiu_[r] = 1.0;
         if (!row_present<KIND>(r)) continue;
-        ll[r] = ldw(L, k, M::LAML + r);
-        lu[r] = ldw(L, k, M::LAMU + r);
-        tl[r] = ldw(L, k, M::TL + r);
-        tu[r] = ldw(L, k, M::TU + r);
+        ll[r] = ldw<KIND>(L, k, M::LAML + r);
+        lu[r] = ldw<KIND>(L, k, M::LAMU + r);
+        tl[r] = ldw<KIND>(L, k, M::TL + r);
+        tu[r] = ldw<KIND>(L, k, M::TU + r);
         if (MPCX_STORE_RECIP) {
-            til_[r] = ldw(L, k, M::TIL + r);
-            tiu_[r] = ldw(L, k, M::TIU + r);
+            til_[r] = ldw<KIND>(L, k, M::TIL + r);
+            tiu_[r] = ldw<KIND>(L, k, M::TIU + r);
         }
     }
     AB &ab = in.ab;
@@ -823,9 +845,9 @@ DEV void stage_B0_head(const Lane &L, int k, const Step &sp, B0In<NH> &in, const
 #pragma unroll
     for (int i = 0; i < NX; ++i) bv[i] = 0.0;
     if (KIND != LAST) {
-        load_ab<NH>(L, k, ab);
+        load_ab<NH, KIND>(L, k, ab);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) bv[i] = ldw(L, k, M::BV + i);
+        for (int i = 0; i < NX; ++i) bv[i] = ldw<KIND>(L, k, M::BV + i);
     }
     __builtin_amdgcn_sched_barrier(0);     // every load of the stage is in flight before the first use
     // ---- pending step on the primal and the dynamics multiplier ----
@@ -834,7 +856,7 @@ DEV void stage_B0_head(const Lane &L, int k, const Step &sp, B0In<NH> &in, const
         v[j] = vo[j];
         if (var_present<KIND>(j)) {
             v[j] = (sp.have && var_on<KIND>(kr, j)) ? fma(sp.alpha, dv[j], vo[j]) : vo[j];
-            stw(L, k, M::V + j, v[j]);
+            stw<KIND>(L, k, M::V + j, v[j]);
         }
     }
     if (KIND != FIRST) {
@@ -842,7 +864,7 @@ DEV void stage_B0_head(const Lane &L, int k, const Step &sp, B0In<NH> &in, const
         for (int i = 0; i < NX; ++i) {
             qpi[i] = sp.have ? fma(sp.alpha, dpi[i], qpi[i]) : qpi[i];
             qpi[i] = is_first<KIND>(kr) ? 0.0 : qpi[i];
-            stw(L, k, M::QPI + i, qpi[i]);
+            stw<KIND>(L, k, M::QPI + i, qpi[i]);
         }
     }
 }
@@ -909,10 +931,10 @@ DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
             t = fma(sp.alpha, dlu, l_u); t = (t < o.lam_min) ? o.lam_min : t; l_u = sp.have ? t : l_u;
             t = fma(sp.alpha, dtl, t_l); t = (t < o.t_min) ? o.t_min : t; t_l = sp.have ? t : t_l;
             t = fma(sp.alpha, dtu, t_u); t = (t < o.t_min) ? o.t_min : t; t_u = sp.have ? t : t_u;
-            stw(L, k, M::LAML + r, l_l);
-            stw(L, k, M::LAMU + r, l_u);
-            stw(L, k, M::TL + r, t_l);
-            stw(L, k, M::TU + r, t_u);
+            stw<KIND>(L, k, M::LAML + r, l_l);
+            stw<KIND>(L, k, M::LAMU + r, l_u);
+            stw<KIND>(L, k, M::TL + r, t_l);
+            stw<KIND>(L, k, M::TU + r, t_u);
         }
         double jv = jdot(r, jx, jy, v);
         double dlm = l_u - l_l;
@@ -933,8 +955,8 @@ DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
         // affine right-hand side and barrier Hessian
         double til = 1.0 / t_l, tiu = 1.0 / t_u;
         if (MPCX_STORE_RECIP) {
-            stw(L, k, M::TIL + r, til);
-            stw(L, k, M::TIU + r, tiu);
+            stw<KIND>(L, k, M::TIL + r, til);
+            stw<KIND>(L, k, M::TIU + r, tiu);
         }
         double ql = fma(-l_l, rdl, ml) * til;
         double qu = fma(-l_u, rdu, mu_) * tiu;
@@ -954,7 +976,7 @@ DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
     double gt[NZ];
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
-        stw(L, k, M::RG + j, rg[j]);
+        stw<KIND>(L, k, M::RG + j, rg[j]);
         if (var_present<KIND>(j)) out.ng = var_on<KIND>(kr, j) ? dmax(out.ng, dabs(rg[j])) : out.ng;
         gt[j] = rg[j];
     }
@@ -980,7 +1002,7 @@ DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
     #pragma unroll
         for (int i = 0; i < NX; ++i) {
             out.rb[i] = out.rb[i] - vxn[i];
-            stw(L, k, M::RB + i, out.rb[i]);
+            stw<KIND>(L, k, M::RB + i, out.rb[i]);
             out.nb = is_last<KIND>(kr) ? out.nb : dmax(out.nb, dabs(out.rb[i]));
         }
     }
@@ -1108,26 +1130,26 @@ DEV void stage_B0_ric(const Lane &L, const B0Out &in, const double *Pn, const do
 }
 
 // the factors of stage k and its cost-to-go Hessian go to the workspace
-template <int NH>
+template <int NH, int KIND>
 DEV void store_ric(const Lane &L, int k, bool factors, bool hessian, const RicOut &ro, const double *Pn)
 {
     typedef Map<NH> M;
     if (factors) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            stw(L, k, M::PRB + i, ro.prb[i]);
-            stw(L, k, M::K + i, ro.K[0][i]);
-            stw(L, k, M::K + NX + i, ro.K[1][i]);
+            stw<KIND>(L, k, M::PRB + i, ro.prb[i]);
+            stw<KIND>(L, k, M::K + i, ro.K[0][i]);
+            stw<KIND>(L, k, M::K + NX + i, ro.K[1][i]);
         }
-        stw(L, k, M::LDL + 0, ro.l10);
-        stw(L, k, M::LDL + 1, ro.d0);
-        stw(L, k, M::LDL + 2, ro.d1);
-        stw(L, k, M::KV + 0, ro.kv[0]);
-        stw(L, k, M::KV + 1, ro.kv[1]);
+        stw<KIND>(L, k, M::LDL + 0, ro.l10);
+        stw<KIND>(L, k, M::LDL + 1, ro.d0);
+        stw<KIND>(L, k, M::LDL + 2, ro.d1);
+        stw<KIND>(L, k, M::KV + 0, ro.kv[0]);
+        stw<KIND>(L, k, M::KV + 1, ro.kv[1]);
     }
     if (hessian) {
 #pragma unroll
-        for (int i = 0; i < 15; ++i) stw(L, k, M::P + i, Pn[i]);
+        for (int i = 0; i < 15; ++i) stw<KIND>(L, k, M::P + i, Pn[i]);
     }
 }
 
@@ -1151,7 +1173,7 @@ __device__ __attribute__((noinline)) void sweep_B0(Lane L, PC<NH> pc, const mpcx
         stage_B0_rows<NH, KIND>(L, o, pc, kk, sp, vxn, qpin, t);                       \
         RicOut ro;                                                                     \
         stage_B0_ric<KIND>(L, t, Pn, pn, Pn, pn, ro);                                  \
-        store_ric<NH>(L, kk, KIND != LAST, KIND != FIRST, ro, Pn);                     \
+        store_ric<NH, KIND>(L, kk, KIND != LAST, KIND != FIRST, ro, Pn);                     \
         ng = dmax(ng, t.ng); nb = dmax(nb, t.nb); nd = dmax(nd, t.nd); nm = dmax(nm, t.nm); \
         sum = sum + t.ssum;                                                            \
         _Pragma("unroll") for (int i = 0; i < NX; ++i) { vxn[i] = t.vx[i]; qpin[i] = t.qpi[i]; } \
@@ -1183,21 +1205,21 @@ DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
     load_xu<NH, KIND>(L, k, kr, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
-        v[j] = ldw(L, k, M::V + j);
-        dva[j] = ldw(L, k, M::DVA + j);
-        gt1[j] = ldw(L, k, M::RG + j);
+        v[j] = ldw<KIND>(L, k, M::V + j);
+        dva[j] = ldw<KIND>(L, k, M::DVA + j);
+        gt1[j] = ldw<KIND>(L, k, M::RG + j);
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
         ll[r] = lu[r] = tl[r] = tu[r] = til_[r] = tiu_[r] = 1.0;
         if (!row_present<KIND>(r)) continue;
-        ll[r] = ldw(L, k, M::LAML + r);
-        lu[r] = ldw(L, k, M::LAMU + r);
-        tl[r] = ldw(L, k, M::TL + r);
-        tu[r] = ldw(L, k, M::TU + r);
+        ll[r] = ldw<KIND>(L, k, M::LAML + r);
+        lu[r] = ldw<KIND>(L, k, M::LAMU + r);
+        tl[r] = ldw<KIND>(L, k, M::TL + r);
+        tu[r] = ldw<KIND>(L, k, M::TU + r);
         if (MPCX_STORE_RECIP) {
-            til_[r] = ldw(L, k, M::TIL + r);
-            tiu_[r] = ldw(L, k, M::TIU + r);
+            til_[r] = ldw<KIND>(L, k, M::TIL + r);
+            tiu_[r] = ldw<KIND>(L, k, M::TIU + r);
         }
     }
     out.ab = AB{};
@@ -1205,16 +1227,16 @@ DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
 #pragma unroll
     for (int i = 0; i < NX; ++i) { out.prb[i] = 0.0; out.k0[i] = 0.0; out.k1[i] = 0.0; }
     if (KIND != LAST) {
-        load_ab<NH>(L, k, out.ab);
+        load_ab<NH, KIND>(L, k, out.ab);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            out.prb[i] = ldw(L, k, M::PRB + i);
-            out.k0[i] = ldw(L, k, M::K + i);
-            out.k1[i] = ldw(L, k, M::K + NX + i);
+            out.prb[i] = ldw<KIND>(L, k, M::PRB + i);
+            out.k0[i] = ldw<KIND>(L, k, M::K + i);
+            out.k1[i] = ldw<KIND>(L, k, M::K + NX + i);
         }
-        out.l10 = ldw(L, k, M::LDL + 0);
-        out.d0 = ldw(L, k, M::LDL + 1);
-        out.d1 = ldw(L, k, M::LDL + 2);
+        out.l10 = ldw<KIND>(L, k, M::LDL + 0);
+        out.d0 = ldw<KIND>(L, k, M::LDL + 1);
+        out.d1 = ldw<KIND>(L, k, M::LDL + 2);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1282,17 +1304,17 @@ DEV void stage_Bs_rec(const Lane &L, const BsOut &in, double *pn1, double *pn2, 
     }
 }
 
-template <int NH>
+template <int NH, int KIND>
 DEV void store_rec(const Lane &L, int k, bool ff, bool grad, const double (*kvo)[NU], const double *pn1, const double *pn2)
 {
     typedef Map<NH> M;
     if (ff) {
-        stw(L, k, M::KV + 0, kvo[0][0]);  stw(L, k, M::KV + 1, kvo[0][1]);
-        stw(L, k, M::KV2 + 0, kvo[1][0]); stw(L, k, M::KV2 + 1, kvo[1][1]);
+        stw<KIND>(L, k, M::KV + 0, kvo[0][0]);  stw<KIND>(L, k, M::KV + 1, kvo[0][1]);
+        stw<KIND>(L, k, M::KV2 + 0, kvo[1][0]); stw<KIND>(L, k, M::KV2 + 1, kvo[1][1]);
     }
     if (grad) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { stw(L, k, M::PV + i, pn1[i]); stw(L, k, M::PV2 + i, pn2[i]); }
+        for (int i = 0; i < NX; ++i) { stw<KIND>(L, k, M::PV + i, pn1[i]); stw<KIND>(L, k, M::PV2 + i, pn2[i]); }
     }
 }
 
@@ -1304,7 +1326,7 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, do
     stage_Bs_rows<NH, KIND>(L, o, pc, k, sigma_mu, t);
     double kvo[2][NU];
     stage_Bs_rec<KIND>(L, t, pn1, pn2, kvo);
-    store_rec<NH>(L, k, KIND != LAST, KIND != FIRST, kvo, pn1, pn2);
+    store_rec<NH, KIND>(L, k, KIND != LAST, KIND != FIRST, kvo, pn1, pn2);
 }
 
 template <int NH>
@@ -1371,20 +1393,20 @@ DEV void stage_F_load(const Lane &L, int k, FIn<NH, NS> &in, const KR &kr = KR{f
     load_xu<NH, KIND>(L, k, kr, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
-        v[j] = ldw(L, k, M::V + j);
-        dva[j] = (NS == 1) ? 0.0 : ldw(L, k, M::DVA + j);
+        v[j] = ldw<KIND>(L, k, M::V + j);
+        dva[j] = (NS == 1) ? 0.0 : ldw<KIND>(L, k, M::DVA + j);
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
         ll[r] = lu[r] = tl[r] = tu[r] = til_[r] = tiu_[r] = 1.0;
         if (!row_present<KIND>(r)) continue;
-        ll[r] = ldw(L, k, M::LAML + r);
-        lu[r] = ldw(L, k, M::LAMU + r);
-        tl[r] = ldw(L, k, M::TL + r);
-        tu[r] = ldw(L, k, M::TU + r);
+        ll[r] = ldw<KIND>(L, k, M::LAML + r);
+        lu[r] = ldw<KIND>(L, k, M::LAMU + r);
+        tl[r] = ldw<KIND>(L, k, M::TL + r);
+        tu[r] = ldw<KIND>(L, k, M::TU + r);
         if (MPCX_STORE_RECIP) {
-            til_[r] = ldw(L, k, M::TIL + r);
-            tiu_[r] = ldw(L, k, M::TIU + r);
+            til_[r] = ldw<KIND>(L, k, M::TIL + r);
+            tiu_[r] = ldw<KIND>(L, k, M::TIU + r);
         }
     }
     AB &ab = in.ab;
@@ -1395,26 +1417,26 @@ DEV void stage_F_load(const Lane &L, int k, FIn<NH, NS> &in, const KR &kr = KR{f
 #pragma unroll
     for (int q = 0; q < NS; ++q) { kv[q][0] = 0.0; kv[q][1] = 0.0; }
     if (KIND != LAST) {
-        load_ab<NH>(L, k, ab);
+        load_ab<NH, KIND>(L, k, ab);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            rb[i] = ldw(L, k, M::RB + i);
-            kg[0][i] = ldw(L, k, M::K + i);
-            kg[1][i] = ldw(L, k, M::K + NX + i);
+            rb[i] = ldw<KIND>(L, k, M::RB + i);
+            kg[0][i] = ldw<KIND>(L, k, M::K + i);
+            kg[1][i] = ldw<KIND>(L, k, M::K + NX + i);
         }
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
-            kv[q][0] = ldw(L, k, M::KV + q * M::SOL2 + 0);
-            kv[q][1] = ldw(L, k, M::KV + q * M::SOL2 + 1);
+            kv[q][0] = ldw<KIND>(L, k, M::KV + q * M::SOL2 + 0);
+            kv[q][1] = ldw<KIND>(L, k, M::KV + q * M::SOL2 + 1);
         }
     }
     if (NS == 2 && KIND != FIRST) {
 #pragma unroll
         for (int q = 0; q < NS; ++q)
 #pragma unroll
-            for (int i = 0; i < NX; ++i) pv[q][i] = ldw(L, k, M::PV + q * M::SOL2 + i);
+            for (int i = 0; i < NX; ++i) pv[q][i] = ldw<KIND>(L, k, M::PV + q * M::SOL2 + i);
 #pragma unroll
-        for (int i = 0; i < 15; ++i) Pk[i] = ldw(L, k, M::P + i);
+        for (int i = 0; i < 15; ++i) Pk[i] = ldw<KIND>(L, k, M::P + i);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -1442,7 +1464,7 @@ DEV void stage_F_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, in
                 double acc = pv[q][i];
 #pragma unroll
                 for (int j = 0; j < NX; ++j) acc = fma(psym(Pk, i, j), dx[q][j], acc);
-                stw(L, k, M::DPI + q * M::SOL2 + i, acc);
+                stw<KIND>(L, k, M::DPI + q * M::SOL2 + i, acc);
             }
         }
         if (KIND != LAST) {
@@ -1451,7 +1473,7 @@ DEV void stage_F_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, in
             dvk[q][1] = is_last<KIND>(kr) ? 0.0 : dvk[q][1];
         }
 #pragma unroll
-        for (int j = 0; j < NZ; ++j) stw(L, k, (NS == 1 ? M::DVA : M::DV + q * M::SOL2) + j, dvk[q][j]);
+        for (int j = 0; j < NZ; ++j) stw<KIND>(L, k, (NS == 1 ? M::DVA : M::DV + q * M::SOL2) + j, dvk[q][j]);
     }
     double s1k = 0.0, s2k = 0.0, knum[NS], kden[NS];
 #pragma unroll
@@ -1837,7 +1859,7 @@ __device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const
         for (int i = 0; i < NX; ++i) carry[CY_PV + i] = po[i];
     }
     lds_order();
-    if (kj <= N) store_ric<NH>(S, 0, kj < N, kj > 0, ro, Po);
+    if (kj <= N) store_ric<NH, ANY>(S, 0, kj < N, kj > 0, ro, Po);
     SUB_END(19);
 }
 
@@ -1900,7 +1922,7 @@ __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_
 #pragma unroll
         for (int i = 0; i < NX; ++i) { c1[i] = bcast(o1[i], 0); c2[i] = bcast(o2[i], 0); }
         SUB_END(25);
-        if (kj <= N) store_rec<NH>(S, 0, kj < N, kj > 0, kvo, o1, o2);
+        if (kj <= N) store_rec<NH, ANY>(S, 0, kj < N, kj > 0, kvo, o1, o2);
     }
 }
 
@@ -1988,7 +2010,7 @@ __device__ __attribute__((noinline)) void coop_L(Lane C, PC<NH> pc, const mpcx_o
         if (kj <= N) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                const double x0 = ldw(S, 0, M::X + i), v0 = ldw(S, 0, M::V + NU + i), q0 = ldw(S, 0, M::QPI + i);
+                const double x0 = ldw<ANY>(S, 0, M::X + i), v0 = ldw<ANY>(S, 0, M::V + NU + i), q0 = ldw<ANY>(S, 0, M::QPI + i);
                 xk[i] = first ? x0 : x0 + v0;
                 pik[i] = (kj > 0) ? q0 : 0.0;
             }
@@ -1997,9 +2019,9 @@ __device__ __attribute__((noinline)) void coop_L(Lane C, PC<NH> pc, const mpcx_o
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const Lane S1 = stage_lane(C, (unsigned)kj + 1u);
-                nxt[i] = ldw(S1, 0, M::X + i);
-                nxt[NX + i] = ldw(S1, 0, M::V + NU + i);
-                nxt[2 * NX + i] = ldw(S1, 0, M::QPI + i);
+                nxt[i] = ldw<ANY>(S1, 0, M::X + i);
+                nxt[NX + i] = ldw<ANY>(S1, 0, M::V + NU + i);
+                nxt[2 * NX + i] = ldw<ANY>(S1, 0, M::QPI + i);
             }
         }
         coop_sync();
@@ -2217,10 +2239,10 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             for (int f0 = 0; f0 < M::F; f0 += 16) {
                 double tmp[16];
 #pragma unroll
-                for (int f = 0; f < 16; ++f) tmp[f] = (f0 + f < M::F) ? ldw(S, 0, f0 + f) : 0.0;
+                for (int f = 0; f < 16; ++f) tmp[f] = (f0 + f < M::F) ? ldw<ANY>(S, 0, f0 + f) : 0.0;
 #pragma unroll
                 for (int f = 0; f < 16; ++f)
-                    if (f0 + f < M::F) stw(D, 0, f0 + f, tmp[f]);
+                    if (f0 + f < M::F) stw<ANY>(D, 0, f0 + f, tmp[f]);
             }
         }
         if ((int)threadIdx.x == p) { L.roff = R.lane; solo = true; }
@@ -2263,8 +2285,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                     const Lane S = stage_lane(C, (unsigned)kj);
                     double xo[NX], uo[NU] = {0.0, 0.0};
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) xo[i] = ldw(S, 0, M::X + i);
-                    if (kj < N) { uo[0] = ldw(S, 0, M::U + 0); uo[1] = ldw(S, 0, M::U + 1); }
+                    for (int i = 0; i < NX; ++i) xo[i] = ldw<ANY>(S, 0, M::X + i);
+                    if (kj < N) { uo[0] = ldw<ANY>(S, 0, M::U + 0); uo[1] = ldw<ANY>(S, 0, M::U + 1); }
 #pragma unroll
                     for (int i = 0; i < NX; ++i) out.X[(b * (size_t)(N + 1) + kj) * NX + i] = xo[i];
                     if (kj < N) {
@@ -2344,20 +2366,20 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                     for (int i = 0; i < NX; ++i) xg[i] = in.xguess[((size_t)kj * NX + i) * L.B + b];
 #pragma unroll
                     for (int i = 0; i < NX; ++i) {
-                        stw(S, 0, M::X + i, xg[i]);
-                        stw(S, 0, M::QPI + i, 0.0);
+                        stw<ANY>(S, 0, M::X + i, xg[i]);
+                        stw<ANY>(S, 0, M::QPI + i, 0.0);
                     }
                     double ug[NU] = {0.0, 0.0};
                     if (in.uguess && kj < N) {
                         ug[0] = in.uguess[((size_t)kj * NU + 0) * L.B + b];
                         ug[1] = in.uguess[((size_t)kj * NU + 1) * L.B + b];
                     }
-                    stw(S, 0, M::U + 0, ug[0]);
-                    stw(S, 0, M::U + 1, ug[1]);
+                    stw<ANY>(S, 0, M::U + 0, ug[0]);
+                    stw<ANY>(S, 0, M::U + 1, ug[1]);
 #pragma unroll
                     for (int r = 0; r < M::R; ++r) {
-                        stw(S, 0, M::LAML + r, 0.0);
-                        stw(S, 0, M::LAMU + r, 0.0);
+                        stw<ANY>(S, 0, M::LAML + r, 0.0);
+                        stw<ANY>(S, 0, M::LAMU + r, 0.0);
                     }
                 }
             }
