@@ -9,7 +9,8 @@
 //    linearisation, multipliers and Riccati factors of all N+1 stages, ~1.2 KB per
 //    stage) cannot live on chip: it sits in an HBM workspace laid out
 //    [wave][stage][field][lane], so each wavefront load/store is one contiguous
-//    512-byte segment, and the solver is organised as a few fused forward/backward
+//    512-byte segment (with the non-temporal hint: nothing is reused before megabytes
+//    have passed), and the solver is organised as a few fused forward/backward
 //    SWEEPS over the stages that touch each field as rarely as possible:
 //
 //      L   forward : apply the SQP step, RK4 + sensitivities, NLP residuals,
