@@ -195,6 +195,40 @@ def test_no_silent_cpu_fallback():
     assert find_path(e, s) is None             # find_path never raises (reference :559-562)
 
 
+def test_results_carry_what_the_reference_plots_read(oracle):
+    """Consumer side: everything reference plots.py reads from a result dict and its EgoConfig
+    (:20-22 t/x/u, :31-32 start/goal, :45-56 obstacles, :72 corridor_cal on the two points and the
+    width, :130-164 the bound attributes, :212/:248-249 grid entries) is there with the type and
+    shape those lines index."""
+    e, s = cases.make_scenario("line")
+    e.obstacles = None
+    r = find_path(e, s, solver=oracle.solve_packed)
+    N = int(s.duration / s.dt)
+    assert set(r) >= {"t", "x", "u", "status"}
+    assert r["t"].shape == (N + 1,) and r["x"].shape == (N + 1, 5) and r["u"].shape == (N, 2)
+    assert r["x"].dtype == np.float64 and r["x"][:, 0:5].shape == (N + 1, 5) and r["u"][:, 1].shape == (N,)
+    assert len(e.state_start) == 5 and len(e.state_final) == 5
+    assert hasattr(e, "obstacles") and e.obstacles is None
+    assert len(corridor_cal((e.state_start[0], e.state_start[1]), (e.state_final[0], e.state_final[1]),
+                            e.corridor_width)) == 6
+    for name in ("velocity", "steering", "acceleration", "steering_rate"):
+        lo, hi = getattr(e, name + "_min"), getattr(e, name + "_max")
+        assert float(lo) < float(hi)
+    np.rad2deg(e.state_final[2]), np.rad2deg(e.steering_max)
+    # an obstacle is (x, y, radius, margin), as the circles are drawn (:46-54)
+    eo, so = cases.make_scenario("line")
+    eo.obstacles = [[5.0, 3.0, 1.0, 0.5]]
+    assert all(len(o) == 4 for o in eo.obstacles)
+    # grid entries (:212, :248-249)
+    from mpc_amd.grid_path_plan import grid_path_planning
+    got = grid_path_planning(0.0, 0.0, 0.0, grid_size=40, grid_step=40, num_angles=1,
+                             solver=oracle.solve_packed, verbose=False)
+    assert len(got) >= 1
+    for g in got:
+        assert set(g) == {"start", "results", "ego"} and len(g["start"]) == 3
+        assert g["results"]["x"].shape[1] == 5 and g["ego"].state_final[:2] == [0.0, 0.0]
+
+
 def test_result_files_load_like_the_reference(oracle, tmp_path):
     """Files written by scenarios.main load the way reference create_animation.py:10-14 loads
     them (own files, so unpickling is safe) and embed EgoConfig under module name core_solver."""
