@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--seed", type=int, default=None, help="batch seed of rank 0 (default: the headline seed)")
     ap.add_argument("--obstacle", action="store_true",
                     help="second workload: one obstacle (r=1, margin 0.5) beside the middle of every path")
+    ap.add_argument("--order", default=None, help="experiment: permute the batch before upload (align | align2 | reverse)")
     ap.add_argument("--lib", default=None, help="another build of the library (diagnostic builds)")
     ap.add_argument("--cpu-sample", type=int, default=262144, help="problems timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
@@ -61,6 +62,26 @@ def main():
     seed0 = SEED if args.seed is None else args.seed
     packed = synthetic_batch(B, seed=seed0 + rank, obstacle=args.obstacle)
     N = packed.N
+    if args.order:
+        from mpc_amd.batch import F_X0, F_GOAL
+        sx, sy, sth = packed.pdata[F_X0], packed.pdata[F_X0 + 1], packed.pdata[F_X0 + 2]
+        gx, gy, gth = packed.pdata[F_GOAL], packed.pdata[F_GOAL + 1], packed.pdata[F_GOAL + 2]
+        phi = np.arctan2(gy - sy, gx - sx)
+        wrap = lambda a: (a + np.pi) % (2 * np.pi) - np.pi
+        score = np.abs(wrap(phi - sth)) + np.abs(wrap(gth - phi))
+        if args.order == "align":
+            perm = np.argsort(score, kind="stable")
+        elif args.order == "align2":      # the aligned fifth first, in the given order; then the others
+            first = score <= np.quantile(score, 0.2)
+            perm = np.concatenate([np.nonzero(first)[0], np.nonzero(~first)[0]])
+        elif args.order == "align3":     # aligned AND short manoeuvres first
+            dist = np.hypot(gx - sx, gy - sy)
+            first = (score <= np.quantile(score, 0.17)) & (dist < 4.3)
+            perm = np.concatenate([np.nonzero(first)[0], np.nonzero(~first)[0]])
+        else:
+            perm = np.arange(B)[::-1].copy()
+        packed = type(packed)(B, N, np.ascontiguousarray(packed.pdata[:, perm]), np.ascontiguousarray(packed.n_obs[perm]),
+                              np.ascontiguousarray(packed.xguess[:, :, perm]), packed.duration)
 
     # inputs resident in HBM before the timed region
     d_pd = torch.from_numpy(packed.pdata).to(dev)

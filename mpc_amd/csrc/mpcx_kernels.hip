@@ -135,6 +135,36 @@ struct Lane {
     double h, hh, h6, hB, invL;
 };
 
+// What a non-inlined single-problem sweep needs of a Lane and of the problem constants.  The
+// calling convention hands structs of this size over in scratch memory, a round trip per call
+// that costs microseconds on a busy GPU and four to five calls make an iteration; as separate
+// scalar parameters (COOP_PARAMS, at most 32 registers with the other arguments) they travel
+// in registers.
+#define COOP_PARAMS                                                                                  \
+    gdouble *a_wave, unsigned a_lane, unsigned a_region, int a_N, int a_nobs, int a_F, double a_h,   \
+        double a_hh, double a_h6, double a_hB, double a_invL, ldouble *a_pcp, double a_lmk
+#define COOP_UNPACK(NH_)                                                                             \
+    const Lane C = lane_of(LaneArgs{a_wave, a_lane, a_region, a_N, a_nobs, a_F, a_h, a_hh, a_h6, a_hB, a_invL}); \
+    PC<NH_> pc;                                                                                      \
+    pc.p = a_pcp;                                                                                    \
+    pc.lmk = a_lmk
+#define COOP_PASS(C_, pc_)                                                                           \
+    (C_).wave, (C_).lane, (C_).region, (C_).N, (C_).nobs, (C_).F, (C_).h, (C_).hh, (C_).h6, (C_).hB, (C_).invL, \
+        (pc_).p, (pc_).lmk
+struct LaneArgs {
+    gdouble *wave;
+    unsigned lane, region;
+    int N, nobs, F;
+    double h, hh, h6, hB, invL;
+};
+__device__ __forceinline__ Lane lane_of(const LaneArgs &a)
+{
+    Lane L;
+    L.wave = a.wave; L.pdata = nullptr; L.B = 0; L.lane = a.lane; L.region = a.region; L.roff = 0; L.b = 0;
+    L.N = a.N; L.nobs = a.nobs; L.F = a.F; L.h = a.h; L.hh = a.hh; L.h6 = a.h6; L.hB = a.hB; L.invL = a.invL;
+    return L;
+}
+
 // The wave-uniform part of every address stays in scalar registers; only the
 // lane (or problem) index is a vector offset.
 // (a 32-bit byte offset on a uniform base is the addressing mode global_load has: base in
@@ -1775,9 +1805,10 @@ DEV void lds_order()
 // one block of 64 consecutive stages (k0 .. k0+63) of sweep B0; what the block above handed
 // down, and the running reductions, are read from and left in the carry words
 template <int NH, bool ONE>
-__device__ __attribute__((noinline)) void coop_B0_block(Lane C, PC<NH> pc, const mpcx_opts *op, bool sp_have, int sp_mode,
+__device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, const mpcx_opts *op, bool sp_have, int sp_mode,
                                                         double sp_sigma_mu, double sp_alpha, int k0, ldouble *ret)
 {
+    COOP_UNPACK(NH);
     const mpcx_opts &o = *op;
     Step sp;
     sp.have = sp_have; sp.mode = sp_mode; sp.sigma_mu = sp_sigma_mu; sp.alpha = sp_alpha;
@@ -1873,10 +1904,10 @@ DEV void coop_B0(const Lane &C, const PC<NH> &pc, const mpcx_opts *op, const Ste
     lds_order();
     // blocks of 64 consecutive stages, the last block first
     if (N < 64) {      // a single block: everything handed down from above is zero
-        coop_B0_block<NH, true>(C, pc, op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, 0, ret);
+        coop_B0_block<NH, true>(COOP_PASS(C, pc), op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, 0, ret);
     } else {
         for (int k0 = (N / 64) * 64; k0 >= 0; k0 -= 64)
-            coop_B0_block<NH, false>(C, pc, op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, k0, ret);
+            coop_B0_block<NH, false>(COOP_PASS(C, pc), op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, k0, ret);
     }
     lds_order();
     const double ng = carry[CY_NORM + 0], nb = carry[CY_NORM + 1], nd = carry[CY_NORM + 2], nm = carry[CY_NORM + 3],
@@ -1886,8 +1917,9 @@ DEV void coop_B0(const Lane &C, const PC<NH> &pc, const mpcx_opts *op, const Ste
 }
 
 template <int NH, bool ONE>
-__device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_opts *op, double sigma_mu)
+__device__ __attribute__((noinline)) void coop_Bs(COOP_PARAMS, const mpcx_opts *op, double sigma_mu)
 {
+    COOP_UNPACK(NH);
     const mpcx_opts &o = *op;
     const int N = C.N;
     const int j = (int)threadIdx.x;
@@ -1928,8 +1960,9 @@ __device__ __attribute__((noinline)) void coop_Bs(Lane C, PC<NH> pc, const mpcx_
 }
 
 template <int NH, int NS, bool ONE>
-__device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx_opts *op, double sigma_mu, ldouble *ret)
+__device__ __attribute__((noinline)) double coop_F(COOP_PARAMS, const mpcx_opts *op, double sigma_mu, ldouble *ret)
 {
+    COOP_UNPACK(NH);
     const mpcx_opts &o = *op;
     const int N = C.N;
     const int j = (int)threadIdx.x;
@@ -1993,9 +2026,10 @@ __device__ __attribute__((noinline)) double coop_F(Lane C, PC<NH> pc, const mpcx
 // sweep L has no recursion: every stage is linearised at its own (new) state, which its lane
 // forms from the stage's own iterate and step exactly as the stage before would have
 template <int NH, bool ONE>
-__device__ __attribute__((noinline)) void coop_L(Lane C, PC<NH> pc, const mpcx_opts *op, bool first, ldouble *ret)
+__device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, const mpcx_opts *op, bool first, ldouble *ret)
 {
     typedef Map<NH> M;
+    COOP_UNPACK(NH);
     const mpcx_opts &o = *op;
     const int N = C.N;
     const int j = (int)threadIdx.x;
@@ -2070,8 +2104,11 @@ enum LaneState {
 #endif
 // (coop_max: with this many problems or fewer in progress the wavefront takes them one at a
 // time in single-problem mode.)
+// (disable_tail_calls: a call that is marked as a possible tail call loses the treatment of local
+// functions whose callers are all known, in which no register is callee-saved; the sweeps
+// would then save and restore over a hundred registers through scratch memory on every call)
 template <int NH>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((disable_tail_calls))
 mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
                 int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots)
 {
@@ -2134,8 +2171,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         PC<NH> pcc;
         problem_of_lane<NH>(L, pc, (ldouble *)pc_lds, p, C, pcc);
         const bool fp = __builtin_amdgcn_readlane((int)first, p) != 0;
-        if (N < 64) coop_L<NH, true>(C, pcc, op, fp, ret);
-        else coop_L<NH, false>(C, pcc, op, fp, ret);
+        if (N < 64) coop_L<NH, true>(COOP_PASS(C, pcc), op, fp, ret);
+        else coop_L<NH, false>(COOP_PASS(C, pcc), op, fp, ret);
         const double r0 = uniform(ret[0 * 64]), r1 = uniform(ret[1 * 64]), r2 = uniform(ret[2 * 64]),
                      r3 = uniform(ret[3 * 64]), r4 = uniform(ret[4 * 64]);
         if ((int)threadIdx.x == p) { res[0] = r0; res[1] = r1; res[2] = r2; res[3] = r3; cost = r4; }
@@ -2172,8 +2209,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             if (qs == 3) { n_status = MPCX_QP_FAILURE; n_state = LS_OUT; }
             else n_state = LS_LIN;
         } else {
-            const double a_aff = uniform((N < 64) ? coop_F<NH, 1, true>(C, pcc, op, 0.0, ret)
-                                                  : coop_F<NH, 1, false>(C, pcc, op, 0.0, ret));
+            const double a_aff = uniform((N < 64) ? coop_F<NH, 1, true>(COOP_PASS(C, pcc), op, 0.0, ret)
+                                                  : coop_F<NH, 1, false>(COOP_PASS(C, pcc), op, 0.0, ret));
             STAMP(13, true);
             const double S1 = uniform(ret[0 * 64]), S2 = uniform(ret[1 * 64]);
             double S0 = mu * (double)mt;
@@ -2182,11 +2219,11 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             double ratio = mu_aff / mu;
             double sigma = ratio * ratio * ratio;
             const double sigma_mu = sigma * mu;
-            if (N < 64) coop_Bs<NH, true>(C, pcc, op, sigma_mu);
-            else coop_Bs<NH, false>(C, pcc, op, sigma_mu);
+            if (N < 64) coop_Bs<NH, true>(COOP_PASS(C, pcc), op, sigma_mu);
+            else coop_Bs<NH, false>(COOP_PASS(C, pcc), op, sigma_mu);
             STAMP(14, true);
-            const double alpha1 = uniform((N < 64) ? coop_F<NH, 2, true>(C, pcc, op, sigma_mu, ret)
-                                                   : coop_F<NH, 2, false>(C, pcc, op, sigma_mu, ret));
+            const double alpha1 = uniform((N < 64) ? coop_F<NH, 2, true>(COOP_PASS(C, pcc), op, sigma_mu, ret)
+                                                   : coop_F<NH, 2, false>(COOP_PASS(C, pcc), op, sigma_mu, ret));
             const double alpha2 = uniform(ret[0 * 64]);
             STAMP(15, true);
             const bool use2 = o.cond_pred_corr && (alpha1 < a_aff);
