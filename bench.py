@@ -69,7 +69,7 @@ def main():
         phi = np.arctan2(gy - sy, gx - sx)
         wrap = lambda a: (a + np.pi) % (2 * np.pi) - np.pi
         score = np.abs(wrap(phi - sth)) + np.abs(wrap(gth - phi))
-        if args.order == "align":
+        if args.order.split("+")[0] == "align":
             perm = np.argsort(score, kind="stable")
         elif args.order == "align2":      # the aligned fifth first, in the given order; then the others
             first = score <= np.quantile(score, 0.2)
@@ -78,8 +78,14 @@ def main():
             dist = np.hypot(gx - sx, gy - sy)
             first = (score <= np.quantile(score, 0.17)) & (dist < 4.3)
             perm = np.concatenate([np.nonzero(first)[0], np.nonzero(~first)[0]])
+        elif args.order.split("+")[0].startswith("counts:"):  # longest first, from the iteration counts a previous run saved
+            perm = np.argsort(-np.load(args.order.split("+")[0][7:]).astype(np.int64), kind="stable")
         else:
             perm = np.arange(B)[::-1].copy()
+        if args.order.endswith("+deal") or os.environ.get("MPCX_BENCH_DEAL"):
+            # deal the head of the order out over the wavefronts (1024 x 64 lanes fetch at time 0)
+            n = min(B, 65536) // 1024 * 1024
+            perm = np.concatenate([perm[:n].reshape(-1, 1024).T.reshape(-1), perm[n:]])
         packed = type(packed)(B, N, np.ascontiguousarray(packed.pdata[:, perm]), np.ascontiguousarray(packed.n_obs[perm]),
                               np.ascontiguousarray(packed.xguess[:, :, perm]), packed.duration)
 
@@ -135,6 +141,8 @@ def main():
     sqp_it = d_si.cpu().numpy()
     qp_it = d_qi.cpu().numpy()
     n_conv = int((status == 0).sum())
+    if os.environ.get("MPCX_BENCH_SAVE_COUNTS"):
+        np.save(os.environ["MPCX_BENCH_SAVE_COUNTS"], qp_it)
     fl = flops.algorithmic_flops(status, sqp_it, qp_it, N)
 
     tot = torch.tensor([elapsed, float(n_conv), fl, float(B)], dtype=torch.float64, device=dev)
@@ -156,13 +164,16 @@ def main():
     steps = max(args.steps, 1)
     value = n_conv_all * steps / elapsed
     achieved_tf = fl / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-    # HBM bytes of one launch from the committed counter passes (same batch only)
+    # Memory-side bytes of one launch from the committed counter passes (same batch only).  FETCH_SIZE
+    # counts half of the bytes of this kernel's loads (64 lanes x 8 B in one 512-byte segment): measured
+    # on the same access shape with a known byte count (profiles/micro/stream_rw, r01_pmc_extra.txt);
+    # WRITE_SIZE is exact for it.
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pmc = json.load(fh)
         if int(pmc["batch"]) == B and not args.obstacle and args.seed is None:
-            traffic = (float(pmc["fetch_kib"]) + float(pmc["write_kib"])) * 1024.0
+            traffic = (float(pmc["read_factor"]) * float(pmc["fetch_kib"]) + float(pmc["write_kib"])) * 1024.0
     except (OSError, ValueError, KeyError):
         pass
     io_bytes = flops.algorithmic_io_bytes(N) * B
@@ -182,6 +193,9 @@ def main():
         "roofline": {"bound": "valu_fp64", "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS,
                      "traffic": traffic,
+                     "traffic_GBs": traffic / (kernel_ms * 1e-3) / 1e9 if traffic and kernel_ms > 0 else None,
+                     "traffic_frac_of_hbm_peak": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                     if traffic and kernel_ms > 0 else None,
                      "kernel": "mpcx_sqp_kernel<1>" if args.obstacle else "mpcx_sqp_kernel<0>", "kernel_ms": kernel_ms,
                      "algorithmic_flops_per_launch": fl,
                      **({"flops_note": "per-iteration constants of the obstacle-free count (a lower bound here)"}

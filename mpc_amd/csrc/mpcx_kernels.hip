@@ -2110,7 +2110,7 @@ enum LaneState {
 template <int NH>
 __global__ void __launch_bounds__(64) __attribute__((disable_tail_calls))
 mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
-                int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots)
+                int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots, unsigned deal)
 {
     const mpcx_opts &o = *op;
     typedef Map<NH> M;
@@ -2356,7 +2356,18 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             STAMP(8, st_e);
             [[maybe_unused]] const bool st_a = (state == LS_FETCH);
             if (state == LS_FETCH) {
-                unsigned b = (unsigned)atomicAdd(counter, 1);
+                // Fetch order.  The batch is taken in the caller's order in blocks of 65536 problems;
+                // inside a block the c-th fetch takes problem (c * g) mod (block size), g coprime to the
+                // size and near its golden-section point, so consecutive fetches lie far apart: problems
+                // that are neighbours in the caller's order (and often alike in length) end up in
+                // different wavefronts.  Results are written at the problem's own index.
+                const unsigned c = (unsigned)atomicAdd(counter, 1);
+                unsigned b = c;
+                if (deal != 0 && c < B) {
+                    const unsigned full = B & ~65535u;
+                    if (c < full) b = (c & ~65535u) | ((c * 40503u) & 65535u);
+                    else b = full + (unsigned)(((unsigned long long)(c - full) * deal) % (B - full));
+                }
                 if (b >= B) {
                     MARK(20);
                     state = LS_DONE;
@@ -2661,14 +2672,29 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     // the source is read when the copy is enqueued only if it is pageable host memory, which `o` is
     e = hipMemcpyAsync(d_opts, &o, sizeof(mpcx_opts), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return e;
+    // fetch order inside the last (partial) block of 65536 problems: a multiplier coprime to its size
+    // near the golden-section point; 0 = the caller's order throughout (MPCX_DEAL=0)
+    unsigned deal = 1;
+    const char *de = getenv("MPCX_DEAL");
+    if (de && atoi(de) == 0) deal = 0;
+    else {
+        const unsigned long long rest = (unsigned long long)in.B & 65535u;
+        if (rest > 2) {
+            unsigned long long g = (unsigned long long)((double)rest * 0.6180339887498949);
+            if (g < 1) g = 1;
+            auto gcd = [](unsigned long long a, unsigned long long b) { while (b) { unsigned long long t = a % b; a = b; b = t; } return a; };
+            while (gcd(g, rest) != 1) ++g;      // rest - 1 is coprime to rest, so this ends below rest
+            deal = (unsigned)g;
+        }
+    }
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal); break;
 #else
     default: return hipErrorInvalidValue;
 #endif

@@ -54,6 +54,20 @@ def test_synthetic_batch_matches_oracle(oracle, B):
     assert (ref["status"] == 0).any() or B < 20
 
 
+def test_fetch_order_leaves_no_trace(oracle, monkeypatch):
+    """One full block of 65536 problems plus a ragged one: the dealt fetch order (default) and the
+    caller's order (MPCX_DEAL=0) give the oracle's results at every problem's own index."""
+    B = 65536 + 1237
+    packed = synthetic_batch(B)
+    dealt = _lib.solve_packed(packed)
+    monkeypatch.setenv("MPCX_DEAL", "0")
+    plain = _lib.solve_packed(packed)
+    monkeypatch.delenv("MPCX_DEAL")
+    cases.assert_same_solution(dealt, plain, "dealt fetch vs caller's order")
+    ref = oracle.solve_packed(packed)
+    cases.assert_same_solution(dealt, ref, f"synthetic B={B}")
+
+
 @pytest.mark.parametrize("B", [64, 3000])
 def test_synthetic_obstacle_batch_matches_oracle(oracle, B):
     """The benchmark's second workload: one obstacle per problem beside the middle of the path."""
