@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1_000_000, help="problems per GPU")
     ap.add_argument("--seed", type=int, default=None, help="batch seed of rank 0 (default: the headline seed)")
+    ap.add_argument("--same-batch", action="store_true",
+                    help="every rank solves rank 0's batch (per-GPU work identical; default: seed + rank)")
     ap.add_argument("--obstacle", action="store_true",
                     help="second workload: one obstacle (r=1, margin 0.5) beside the middle of every path")
     ap.add_argument("--order", default=None, help="experiment: permute the batch before upload (align | align2 | reverse)")
@@ -60,7 +62,7 @@ def main():
 
     B = args.batch
     seed0 = SEED if args.seed is None else args.seed
-    packed = synthetic_batch(B, seed=seed0 + rank, obstacle=args.obstacle)
+    packed = synthetic_batch(B, seed=seed0 + (0 if args.same_batch else rank), obstacle=args.obstacle)
     N = packed.N
     if args.order:
         from mpc_amd.batch import F_X0, F_GOAL
@@ -185,7 +187,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{B} random start/goal pose OCPs per GPU, N=50, "
-                               + ("one obstacle each" if args.obstacle else "no obstacles") + f", seed {seed0}+rank",
+                               + ("one obstacle each" if args.obstacle else "no obstacles") + (f", seed {seed0} on every rank" if args.same_batch else f", seed {seed0}+rank"),
                    "problems_per_gpu": B, "N": N, "problems_total": int(B_all),
                    "converged_fraction": n_conv_all / B_all,
                    "solved_per_sec_all_statuses": B_all * steps / elapsed,
