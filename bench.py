@@ -139,13 +139,21 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if ev else 0.0
 
+    # outcome counters reduced on the device (the per-problem arrays are only downloaded for the CPU sample)
+    d_stats = torch.empty(8, dtype=torch.int64, device=dev)
+    if lib.mpcx_batch_stats_device(d_st.data_ptr(), d_si.data_ptr(), d_qi.data_ptr(), B, d_stats.data_ptr(),
+                                   C.c_void_p(stream.cuda_stream)) != 0:
+        raise RuntimeError(lib.mpcx_last_error().decode())
+    stats = d_stats.cpu().numpy()
+    n_conv = int(stats[0])
     status = d_st.cpu().numpy()
     sqp_it = d_si.cpu().numpy()
     qp_it = d_qi.cpu().numpy()
-    n_conv = int((status == 0).sum())
+    assert n_conv == int((status == 0).sum())
     if os.environ.get("MPCX_BENCH_SAVE_COUNTS"):
         np.save(os.environ["MPCX_BENCH_SAVE_COUNTS"], qp_it)
-    fl = flops.algorithmic_flops(status, sqp_it, qp_it, N)
+    fl = flops.flops_from_stats(stats, N)
+    assert fl == flops.algorithmic_flops(status, sqp_it, qp_it, N)
 
     tot = torch.tensor([elapsed, float(n_conv), fl, float(B)], dtype=torch.float64, device=dev)
     if world > 1:

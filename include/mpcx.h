@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 102
+#define MPCX_VERSION 103
 
 #define MPCX_NX 5       /* state  [x, y, theta, v, delta]        (core_solver.py:131) */
 #define MPCX_NU 2       /* input  [acceleration, steering rate]  (core_solver.py:132) */
@@ -148,6 +148,20 @@ int mpcx_initial_guess_device(const double *pdata, const double *width, int32_t 
                               double *xguess, void *stream);
 int mpcx_initial_guess(const double *pdata, const double *width, int32_t B, int32_t N,
                        double *xguess, int device);
+
+/*
+ * Outcome counters of a solved batch, reduced on the device so that a caller who only needs
+ * the statistics does not download the per-problem arrays.  Replaces the host-side counting of
+ * the reference's loops (grid_path_plan.py:80-92 appends and counts the successes, scenarios.py:
+ * 102-105 stops at the first failure): stats[s] for s = 0..4 = problems that ended with status s,
+ * stats[MPCX_STAT_SQP] = QP solves, stats[MPCX_STAT_QP] = interior-point iterations,
+ * stats[MPCX_STAT_LIN] = linearisations (one per QP solve that did not fail, plus the first).
+ * All pointers are memory of the current HIP device, `stats` holds MPCX_NSTATS int64; the work is
+ * queued on `stream` behind the solve that produced the arrays.
+ */
+enum { MPCX_STAT_SQP = 5, MPCX_STAT_QP = 6, MPCX_STAT_LIN = 7, MPCX_NSTATS = 8 };
+int mpcx_batch_stats_device(const int32_t *status, const int32_t *sqp_iter, const int32_t *qp_iter,
+                            int32_t B, int64_t *stats, void *stream);
 
 /*
  * Diagnostic, no counterpart in the reference: sin and cos of n host doubles,

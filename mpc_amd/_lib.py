@@ -77,6 +77,8 @@ def load_library(path=None):
     lib.mpcx_initial_guess_device.restype = C.c_int
     lib.mpcx_initial_guess.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int]
     lib.mpcx_initial_guess.restype = C.c_int
+    lib.mpcx_batch_stats_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.mpcx_batch_stats_device.restype = C.c_int
     lib.mpcx_probe_sincos.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int]
     lib.mpcx_probe_sincos.restype = C.c_int
     if path is None:

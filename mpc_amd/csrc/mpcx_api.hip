@@ -316,6 +316,22 @@ int mpcx_initial_guess(const double *pdata, const double *width, int32_t B, int3
     return 0;
 }
 
+int mpcx_batch_stats_device(const int32_t *status, const int32_t *sqp_iter, const int32_t *qp_iter, int32_t B,
+                            int64_t *stats, void *stream)
+{
+    if (B < 0) return fail(MPCX_E_BADARG, "need B >= 0 (B=%d)", B);
+    if (!stats || (B > 0 && (!status || !sqp_iter || !qp_iter))) return fail(MPCX_E_BADARG, "null argument");
+    if (mpcx_device_count() <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
+    static_assert(sizeof(long long) == sizeof(int64_t), "int64_t is long long on this ABI");
+    if (B == 0) {
+        HIP_TRY(hipMemsetAsync(stats, 0, MPCX_NSTATS * sizeof(int64_t), static_cast<hipStream_t>(stream)));
+        return 0;
+    }
+    HIP_TRY(mpcx_launch_stats(status, sqp_iter, qp_iter, B, reinterpret_cast<long long *>(stats),
+                              static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int mpcx_probe_sincos(const double *x, int32_t n, double *s, double *c, int device)
 {
     if (!x || !s || !c || n < 0) return fail(MPCX_E_BADARG, "bad probe arguments");

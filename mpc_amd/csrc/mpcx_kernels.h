@@ -27,6 +27,10 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
 // initial guess of obstacle-free problems from the problem table (device pointers)
 hipError_t mpcx_launch_guess(const double *pdata, const double *width, int B, int N, double *xguess, hipStream_t stream);
 
+// outcome counters of a solved batch (device pointers; stats = 8 x int64, zeroed by the launcher)
+hipError_t mpcx_launch_stats(const int32_t *status, const int32_t *sqp_iter, const int32_t *qp_iter, int B,
+                             long long *stats, hipStream_t stream);
+
 // sin/cos exactly as the solver computes them (arithmetic parity tests)
 hipError_t mpcx_launch_probe(const double *xin, int n, double *s, double *c, hipStream_t stream);
 

@@ -2626,6 +2626,31 @@ __global__ void mpcx_guess_kernel(const double *pdata, const double *width, int 
 }
 
 // sin/cos as the solver computes them, for the arithmetic parity tests
+// Outcome counters of a solved batch: stats[0..4] = problems per status 0..4, [5] = QP solves,
+// [6] = interior-point iterations, [7] = linearisations (one after every QP solve that did not
+// fail, plus the first).  One grid-stride pass, a shuffle reduction per wavefront, then one
+// atomic per counter and wavefront.  `stats` must be zero on entry.
+__global__ void __launch_bounds__(256) mpcx_stats_kernel(const int32_t *status, const int32_t *sqp_iter,
+                                                         const int32_t *qp_iter, int B, unsigned long long *stats)
+{
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        const int st = status[b], sq = sqp_iter[b], qp = qp_iter[b];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[k] += (st == k) ? 1u : 0u;
+        acc[5] += (unsigned long long)sq;
+        acc[6] += (unsigned long long)qp;
+        acc[7] += (unsigned long long)sq + ((st == MPCX_QP_FAILURE) ? 0u : 1u);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        unsigned long long v = acc[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(&stats[k], v);
+    }
+}
+
 __global__ void mpcx_probe_kernel(const double *xin, int n, double *s, double *c)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2700,6 +2725,18 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     default: return hipErrorInvalidValue;
 #endif
     }
+    return hipGetLastError();
+}
+
+hipError_t mpcx_launch_stats(const int32_t *status, const int32_t *sqp_iter, const int32_t *qp_iter, int B,
+                             long long *stats, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(stats, 0, 8 * sizeof(long long), stream);
+    if (e != hipSuccess) return e;
+    int blocks = (B + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mpcx_stats_kernel, dim3(blocks), dim3(256), 0, stream, status, sqp_iter, qp_iter, B,
+                       reinterpret_cast<unsigned long long *>(stats));
     return hipGetLastError();
 }
 

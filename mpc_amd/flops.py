@@ -28,6 +28,12 @@ def algorithmic_flops(status, sqp_iter, qp_iter, N):
     return float(N * (F_LIN * n_lin.sum() + F_INIT * sqp.sum() + F_IPM * qp.sum()))
 
 
+def flops_from_stats(stats, N):
+    """The same total from the device-side counters of mpcx_batch_stats_device
+    (stats[5] = QP solves, [6] = interior-point iterations, [7] = linearisations)."""
+    return float(N * (F_LIN * float(stats[7]) + F_INIT * float(stats[5]) + F_IPM * float(stats[6])))
+
+
 # bytes the caller hands over and gets back per problem (N shooting intervals)
 def algorithmic_io_bytes(N):
     return 8 * (70 + (N + 1) * 5) + 4 + 8 * ((N + 1) * 5 + N * 2) + 3 * 4 + 8 * 5

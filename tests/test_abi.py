@@ -26,7 +26,7 @@ def test_exports_match_header():
             "mpcx_probe_sincos"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mpcx.h but not exported"
-    assert lib.mpcx_version() == 102
+    assert lib.mpcx_version() == 103
 
 
 def test_struct_layout_and_defaults():

@@ -54,6 +54,31 @@ def test_synthetic_batch_matches_oracle(oracle, B):
     assert (ref["status"] == 0).any() or B < 20
 
 
+@pytest.mark.parametrize("B", [0, 1, 64, 100003])
+def test_device_batch_stats(B):
+    """Outcome counters reduced on the device against numpy on the same arrays (any int32 values
+    the solver can write: statuses 0..4, iteration counts up to 200 and 10000)."""
+    import ctypes as C
+    import torch
+    from mpc_amd import flops
+    lib = _lib.load_library()
+    rng = np.random.default_rng(B + 11)
+    status = rng.integers(0, 5, B).astype(np.int32)
+    sqp = rng.integers(0, 201, B).astype(np.int32)
+    qp = rng.integers(0, 10001, B).astype(np.int32)
+    dev = torch.device("cuda", 0)
+    d_st, d_sq, d_qp = (torch.from_numpy(a).to(dev) for a in (status, sqp, qp))
+    d_out = torch.full((8,), -1, dtype=torch.int64, device=dev)
+    rc = lib.mpcx_batch_stats_device(d_st.data_ptr(), d_sq.data_ptr(), d_qp.data_ptr(), B, d_out.data_ptr(),
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.mpcx_last_error()
+    got = d_out.cpu().numpy()
+    want = [int((status == k).sum()) for k in range(5)] + [int(sqp.sum(dtype=np.int64)), int(qp.sum(dtype=np.int64)),
+                                                           int(sqp.sum(dtype=np.int64) + (status != 4).sum())]
+    assert got.tolist() == want
+    assert flops.flops_from_stats(got, 50) == flops.algorithmic_flops(status, sqp, qp, 50)
+
+
 def test_fetch_order_leaves_no_trace(oracle, monkeypatch):
     """One full block of 65536 problems plus a ragged one: the dealt fetch order (default) and the
     caller's order (MPCX_DEAL=0) give the oracle's results at every problem's own index."""
