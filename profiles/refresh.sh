@@ -15,3 +15,5 @@ timeout -k 10 300 python3 profiles/grid_full.py >> "$OUT/latency.txt" 2>&1 || ex
 timeout -k 10 300 python3 profiles/rti_latency.py > "$OUT/rti_latency.txt" 2>&1 || exit 1
 timeout -k 10 120 python3 profiles/stamps.py 1000000 > "$OUT/stamps_1M.txt" 2>&1 || exit 1
 timeout -k 10 60 python3 profiles/stamps.py 8 > "$OUT/stamps_B8.txt" 2>&1 || exit 1
+bash profiles/pmc_passes.sh "$OUT/pmc" 1000000 > "$OUT/pmc_summary.txt" 2>&1 || exit 1
+bash profiles/pmc_extra.sh "$OUT/pmc_extra" 1000000 > "$OUT/pmc_extra.txt" 2>&1 || exit 1
