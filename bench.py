@@ -27,8 +27,8 @@ HBM_PEAK_GBS = 8000.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1_000_000, help="problems per GPU")
     ap.add_argument("--seed", type=int, default=None, help="batch seed of rank 0 (default: the headline seed)")
     ap.add_argument("--same-batch", action="store_true",
