@@ -35,7 +35,7 @@ def main():
                     help="every rank solves rank 0's batch (per-GPU work identical; default: seed + rank)")
     ap.add_argument("--obstacle", action="store_true",
                     help="second workload: one obstacle (r=1, margin 0.5) beside the middle of every path")
-    ap.add_argument("--order", default=None, help="experiment: permute the batch before upload (align | align2 | reverse)")
+    ap.add_argument("--order", default=None, help="experiment: permute the batch before upload (align | align2 | align3 | counts:FILE | reverse; +deal)")
     ap.add_argument("--lib", default=None, help="another build of the library (diagnostic builds)")
     ap.add_argument("--cpu-sample", type=int, default=262144, help="problems timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()

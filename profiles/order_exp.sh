@@ -1,3 +1,4 @@
+#!/bin/bash
 # Fetch-order experiment (one gpurun call): run time of the 1 M batch in the caller's order, sorted
 # longest-first by the iteration counts of a first run, and by a geometric guess of difficulty.
 set -u
