@@ -189,7 +189,7 @@ int mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts, mpcx_re
         return fail(MPCX_E_BADARG, "workspace too small: %zu bytes given, at least %zu needed", workspace_bytes, least);
     const Plan plan = plan_for(in->B, in->N, workspace_bytes - 512);
     if ((uintptr_t)workspace % 256 != 0) return fail(MPCX_E_BADARG, "workspace not 256-byte aligned");
-    HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(workspace), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, (opts->rti ? 0 : plan.coop_layout), kSlots,
+    HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(workspace), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, plan.coop_layout, kSlots,
                             static_cast<hipStream_t>(stream)));
     return 0;
 }
@@ -265,7 +265,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     dout.cost = d_co.as<double>();
     dout.res = d_re.as<double>();
 
-    HIP_TRY(mpcx_launch_sqp(nh, din, o, dout, d_ws.as<double>(), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, (o.rti ? 0 : plan.coop_layout), kSlots, nullptr));
+    HIP_TRY(mpcx_launch_sqp(nh, din, o, dout, d_ws.as<double>(), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, plan.coop_layout, kSlots, nullptr));
     HIP_TRY(hipDeviceSynchronize());
 
     HIP_TRY(hipMemcpy(out->X, d_X.p, n_X * 8, hipMemcpyDeviceToHost));

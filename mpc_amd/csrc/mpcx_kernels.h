@@ -18,7 +18,7 @@ size_t mpcx_stage_doubles(int nh);
 // Each wavefront works on at most `lanes` (1..64) problems at a time; with `coop_max` or fewer
 // of them in progress it takes them one at a time, a lane per stage (0 = never); sweep L is
 // done that way whenever `lin_max` or fewer problems of the wavefront wait for it.
-// coop_layout = 1 (only with lanes <= coop_max, not in real-time-iteration mode, and
+// coop_layout = 1 (only with lanes <= coop_max and
 // lanes * ceil((N+1)/64) <= N+1): the wavefront never runs the one-lane-per-problem sweeps and its
 // workspace is laid out per problem, stages contiguous, so that its accesses coalesce.
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,

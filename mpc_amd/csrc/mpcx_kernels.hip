@@ -2175,7 +2175,12 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         else coop_L<NH, false>(COOP_PASS(C, pcc), op, fp, ret);
         const double r0 = uniform(ret[0 * 64]), r1 = uniform(ret[1 * 64]), r2 = uniform(ret[2 * 64]),
                      r3 = uniform(ret[3 * 64]), r4 = uniform(ret[4 * 64]);
-        if ((int)threadIdx.x == p) { res[0] = r0; res[1] = r1; res[2] = r2; res[3] = r3; cost = r4; }
+        // (the second sweep L of a real-time iteration only applies the step and reports the objective:
+        // the residuals handed back are those of the test before the QP)
+        if ((int)threadIdx.x == p) {
+            if (!(o.rti && !fp)) { res[0] = r0; res[1] = r1; res[2] = r2; res[3] = r3; }
+            cost = r4;
+        }
     };
     // one interior-point iteration of the problem of lane p, the wavefront with a lane per stage
     auto single_qp = [&](int p) {
@@ -2447,8 +2452,10 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             if (state == LS_LIN) {
                 if (o.rti && !first) {
                     // real-time iteration: apply the one step, report the new objective
-                    sweep_L<NH>(L, pc, op, false, ret);
-                    cost = ret[4 * 64];
+                    if (!coop_lin && !solo) {
+                        sweep_L<NH>(L, pc, op, false, ret);
+                        cost = ret[4 * 64];
+                    }
                     status = MPCX_SUCCESS;
                     state = LS_OUT;
                 } else {

@@ -159,11 +159,16 @@ def test_sweep_modes_match_oracle(oracle, monkeypatch, duration, lanes):
     cases.assert_same_solution(gpu, ref, f"N={packed.N} lanes={lanes}")
 
 
-def test_rti_server_matches_oracle(oracle):
+@pytest.mark.parametrize("lanes", [None, 3, 20, 64])
+def test_rti_server_matches_oracle(oracle, monkeypatch, lanes):
     """Three receding-horizon ticks of a fleet: what the device solves each tick equals the
     oracle's one-iteration (rti) solve of the same tick inputs, bit for bit; the shift and the
-    plant step move the fleet towards the goal."""
+    plant step move the fleet towards the goal.  Through every scheduling path: one vehicle per
+    wavefront (per-problem regions), a few (single-problem sweeps, regions), 20 and 64 (one lane
+    per vehicle)."""
     from mpc_amd.rti import RtiServer
+    if lanes is not None:
+        monkeypatch.setenv("MPCX_LANES", str(lanes))
     packed = synthetic_batch(4096)
     full = _lib.solve_packed(packed)
     ok = np.nonzero(full["status"] == 0)[0][:300]
