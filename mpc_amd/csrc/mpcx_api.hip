@@ -65,7 +65,7 @@ size_t wave_bytes(int N, int nh)
     return (size_t)((N + 1) + kSlots * ((N + 64) / 64)) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
 }
 
-Plan plan_for(int B, int N, size_t target)
+Plan plan_for(int B, int N, size_t target, bool rti = false)
 {
     const size_t per_wave = wave_bytes(N, MPCX_MAX_OBS);
     size_t cap = target / per_wave;
@@ -73,6 +73,10 @@ Plan plan_for(int B, int N, size_t target)
     if (cap > (size_t)kPlanWaves) cap = kPlanWaves;
     Plan p;
     p.lanes = (int)(((size_t)B + cap - 1) / cap);
+    // One linearisation and one QP per problem (real-time iteration): all problems take about the
+    // same few iterations, so once there are too many per wavefront for single-problem mode the
+    // one-lane-per-problem sweeps are best run full (a sweep costs the same with 16 lanes as with 64).
+    if (rti && p.lanes > kCoopMax) p.lanes = 64;
     // diagnostic knob: MPCX_LANES=n fixes the problems per wavefront (tests use it to run
     // small batches through the one-lane-per-problem sweeps)
     if (const char *e = std::getenv("MPCX_LANES")) {
@@ -187,7 +191,7 @@ int mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts, mpcx_re
     const size_t least = 512 + wave_bytes(in->N, MPCX_MAX_OBS);
     if (!workspace || workspace_bytes < least)
         return fail(MPCX_E_BADARG, "workspace too small: %zu bytes given, at least %zu needed", workspace_bytes, least);
-    const Plan plan = plan_for(in->B, in->N, workspace_bytes - 512);
+    const Plan plan = plan_for(in->B, in->N, workspace_bytes - 512, opts->rti != 0);
     if ((uintptr_t)workspace % 256 != 0) return fail(MPCX_E_BADARG, "workspace not 256-byte aligned");
     HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(workspace), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, plan.coop_layout, kSlots,
                             static_cast<hipStream_t>(stream)));
@@ -223,7 +227,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     Plan plan;
     size_t ws_bytes = 0;
     for (size_t target = default_workspace_target();; target /= 2) {
-        plan = plan_for(in->B, in->N, target);
+        plan = plan_for(in->B, in->N, target, o.rti != 0);
         ws_bytes = 512 + (size_t)plan.waves * wave_bytes(in->N, nh);
         if (d_ws.alloc(ws_bytes) == hipSuccess) break;
         (void)hipGetLastError();
