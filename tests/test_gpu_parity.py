@@ -79,6 +79,45 @@ def test_device_batch_stats(B):
     assert flops.flops_from_stats(got, 50) == flops.algorithmic_flops(status, sqp, qp, 50)
 
 
+def test_full_size_properties():
+    """Properties that need no oracle, on a batch too large for it (300 000 problems, N = 50):
+    every problem's result is the same whatever else is in the batch and wherever it sits (a
+    permuted batch gives the permuted results, bit for bit, and a re-run the same bits); every
+    converged trajectory starts at the start state, closes the RK4 step of every interval and
+    ends in the terminal box to the solver's tolerance, inside the input bounds."""
+    from mpc_amd.batch import F_X0, F_GOAL, F_LBU, F_UBU, F_H, F_L
+    from mpc_amd.rti import plant_step
+    B = 300_000
+    packed = synthetic_batch(B)
+    a = _lib.solve_packed(packed)
+    rng = np.random.default_rng(7)
+    perm = rng.permutation(B)
+    shuffled = type(packed)(B, packed.N, np.ascontiguousarray(packed.pdata[:, perm]),
+                            np.ascontiguousarray(packed.n_obs[perm]),
+                            np.ascontiguousarray(packed.xguess[:, :, perm]), packed.duration)
+    b = _lib.solve_packed(shuffled)
+    again = _lib.solve_packed(packed)
+    cases.assert_same_solution(again, a, "second run")
+    b_back = {k: (v[:, np.argsort(perm)] if k == "res" else v[np.argsort(perm)]) for k, v in b.items()}
+    cases.assert_same_solution(b_back, a, "permuted batch")
+    assert set(np.unique(a["status"])) <= {0, 2, 4}
+    ok = np.nonzero(a["status"] == 0)[0]
+    assert ok.size > 0.05 * B
+    X, U = a["X"][ok], a["U"][ok]
+    pd = packed.pdata[:, ok]
+    tol = 1e-3
+    assert np.array_equal(X[:, 0, :], pd[F_X0:F_X0 + 5].T)
+    gap = 0.0
+    for k in range(packed.N):
+        xn = plant_step(np, X[:, k, :], U[:, k, :], pd[F_H], pd[F_L])
+        gap = max(gap, float(np.abs(xn - X[:, k + 1, :]).max()))
+    assert gap < tol, gap
+    eps = np.array([0.1, 0.1, 0.01, 0.01, 0.01])
+    assert (np.abs(X[:, -1, :] - pd[F_GOAL:F_GOAL + 5].T) <= eps + tol).all()
+    assert (U >= pd[F_LBU:F_LBU + 2].T[:, None, :] - tol).all() and (U <= pd[F_UBU:F_UBU + 2].T[:, None, :] + tol).all()
+    assert (a["res"][:, ok] < tol).all()
+
+
 def test_fetch_order_leaves_no_trace(oracle, monkeypatch):
     """One full block of 65536 problems plus a ragged one: the dealt fetch order (default) and the
     caller's order (MPCX_DEAL=0) give the oracle's results at every problem's own index."""
