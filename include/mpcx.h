@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 103
+#define MPCX_VERSION 104
 
 #define MPCX_NX 5       /* state  [x, y, theta, v, delta]        (core_solver.py:131) */
 #define MPCX_NU 2       /* input  [acceleration, steering rate]  (core_solver.py:132) */
@@ -56,7 +56,9 @@ enum {
     MPCX_F_LH   = 56,  /* 1  lower bound of every obstacle row (core_solver.py:349) */
     MPCX_F_UH   = 57,  /* 1  upper bound of every obstacle row (core_solver.py:351) */
     MPCX_F_OBS  = 58,  /* 3*MPCX_MAX_OBS: ox, oy, (r+margin)^2 per obstacle (:338-340) */
-    MPCX_NFIELDS = 70
+    MPCX_F_CW   = 70,  /* 1  corridor_width: the clamp of the initial guess (core_solver.py:27,486-487);
+                             read only when the library computes the guess (xguess == NULL) */
+    MPCX_NFIELDS = 71
 };
 
 typedef struct mpcx_batch {
@@ -64,7 +66,11 @@ typedef struct mpcx_batch {
     int32_t N;              /* shooting intervals, same for the whole call (:133)     */
     const double  *pdata;   /* [MPCX_NFIELDS][B]                                      */
     const int32_t *n_obs;   /* [B], each 0..MPCX_MAX_OBS                              */
-    const double  *xguess;  /* [N+1][5][B] initial state guess (core_solver.py:477-499) */
+    const double  *xguess;  /* [N+1][5][B] initial state guess (core_solver.py:477-499), or NULL: the
+                               library computes it on the device from the table, for problems
+                               without obstacles only (the obstacle branch :360-473 is the caller's:
+                               a problem with n_obs > 0 and no guess ends with status MPCX_NAN and
+                               zero iterations; the host entry points refuse such a batch)          */
     const double  *uguess;  /* [N][2][B] initial input guess, or NULL = zeros, which is what the
                                reference starts from (it never sets "u"); used by receding-
                                horizon callers that shift the previous solution              */
@@ -128,11 +134,30 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts,
  * memory of the CURRENT HIP device.  Asynchronous: kernels are queued on
  * `stream` (a hipStream_t, NULL = default stream) and the call returns.
  * `workspace` must hold mpcx_workspace_bytes(B, N) bytes, 256-byte aligned.
+ * N is limited by the 32-bit byte offsets the kernels address a wavefront's workspace with:
+ * every solve entry point returns MPCX_E_BADARG for N > mpcx_max_horizon() (about 41 000).
  */
+int    mpcx_max_horizon(void);
 size_t mpcx_workspace_bytes(int32_t B, int32_t N);
 int    mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts,
                                mpcx_result *out, void *workspace,
                                size_t workspace_bytes, void *stream);
+
+/*
+ * The solve of mpcx_solve_batch_device for callers that cannot allocate device memory (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  All pointers in `in` and `out` are memory of the CURRENT HIP
+ * device; the workspace is an array built into the library, MPCX_STATIC_SCRATCH_BYTES of device
+ * memory on every GPU the library is loaded on; the call makes no hipMalloc / hipFree, no copy from
+ * host memory and no other allocating call, and queues its kernels on `stream`.  The first call
+ * on a device looks the array's address up (make it outside a graph capture).
+ * Limits: the scratch must hold one wavefront's share, which bounds N (N <= 630 or so; larger N
+ * returns MPCX_E_BADARG); B is not limited, but only as many wavefronts run as the scratch holds
+ * (11 at N = 50), so large batches are slow here.  All calls on one GPU share the array: calls
+ * that overlap in time on the same GPU (different streams or threads) race and must not be made.
+ */
+#define MPCX_STATIC_SCRATCH_BYTES (64u << 20)
+int mpcx_solve_batch_static(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *out, void *stream);
 
 /*
  * Initial state guess of core_solver.py:477-499 for problems WITHOUT obstacles (its obstacle
@@ -140,7 +165,8 @@ int    mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts,
  * the problem table: node i gets the start-goal interpolation at t = i/N, y clamped to the
  * reference's centre-line formula +- width/2, heading interpolated, v = 1 - t, delta = 0;
  * node N gets the goal state.  Same operations in the same order as the host loop, so the
- * result is bit-identical to it.  width[b] = EgoConfig.corridor_width (core_solver.py:27).
+ * result is bit-identical to it.  width[b] = EgoConfig.corridor_width (core_solver.py:27), or
+ * width == NULL: the table's own MPCX_F_CW column.
  * _device: pdata [MPCX_NFIELDS][B], width [B], xguess [N+1][5][B] are device pointers and the
  * kernel is queued on `stream`; the other form takes host pointers and device `device`.
  */
@@ -148,6 +174,27 @@ int mpcx_initial_guess_device(const double *pdata, const double *width, int32_t 
                               double *xguess, void *stream);
 int mpcx_initial_guess(const double *pdata, const double *width, int32_t B, int32_t N,
                        double *xguess, int device);
+
+enum { MPCX_STAT_SQP = 5, MPCX_STAT_QP = 6, MPCX_STAT_LIN = 7, MPCX_NSTATS = 8 };
+
+/*
+ * Solver handle.  Plays the part of the AcadosOcpSolver object of core_solver.py:354 (created,
+ * solved with, dropped), except that it is not tied to one problem: it owns what a solve needs on
+ * HIP device `device` -- a stream, the device copies of the tables, the workspace, and page-locked
+ * host arrays for the results -- and keeps them from call to call, growing them when a larger
+ * batch comes, so that a caller who solves batch after batch pays for allocation once.
+ *
+ * mpcx_ctx_solve: `in` holds HOST pointers (read during the call only).  On return `out` POINTS
+ * INTO the handle's page-locked result arrays (same layout as mpcx_result everywhere else); they
+ * stay valid until the next mpcx_ctx_solve or mpcx_ctx_destroy on this handle, and the caller
+ * never frees them.  stats (may be NULL) receives the MPCX_NSTATS outcome counters of
+ * mpcx_batch_stats_device.  One call at a time per handle; different handles are independent.
+ */
+typedef struct mpcx_ctx mpcx_ctx;
+int  mpcx_ctx_create(mpcx_ctx **ctx, int device);
+int  mpcx_ctx_solve(mpcx_ctx *ctx, const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *out,
+                    int64_t *stats);
+void mpcx_ctx_destroy(mpcx_ctx *ctx);
 
 /*
  * Outcome counters of a solved batch, reduced on the device so that a caller who only needs
@@ -159,7 +206,6 @@ int mpcx_initial_guess(const double *pdata, const double *width, int32_t B, int3
  * All pointers are memory of the current HIP device, `stats` holds MPCX_NSTATS int64; the work is
  * queued on `stream` behind the solve that produced the arrays.
  */
-enum { MPCX_STAT_SQP = 5, MPCX_STAT_QP = 6, MPCX_STAT_LIN = 7, MPCX_NSTATS = 8 };
 int mpcx_batch_stats_device(const int32_t *status, const int32_t *sqp_iter, const int32_t *qp_iter,
                             int32_t B, int64_t *stats, void *stream);
 

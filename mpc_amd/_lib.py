@@ -45,6 +45,10 @@ class MpcxError(RuntimeError):
     pass
 
 
+MPCX_NFIELDS = 71      # rows of the problem table (include/mpcx.h)
+MPCX_NSTATS = 8
+
+
 _lib = None
 
 
@@ -81,6 +85,18 @@ def load_library(path=None):
     lib.mpcx_batch_stats_device.restype = C.c_int
     lib.mpcx_probe_sincos.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int]
     lib.mpcx_probe_sincos.restype = C.c_int
+    lib.mpcx_max_horizon.restype = C.c_int
+    lib.mpcx_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.mpcx_ctx_create.restype = C.c_int
+    lib.mpcx_ctx_solve.argtypes = [C.c_void_p, C.POINTER(MpcxBatch), C.POINTER(MpcxOpts),
+                                   C.POINTER(MpcxResult), C.c_void_p]
+    lib.mpcx_ctx_solve.restype = C.c_int
+    lib.mpcx_ctx_destroy.argtypes = [C.c_void_p]
+    lib.mpcx_ctx_destroy.restype = None
+    if hasattr(lib, "mpcx_solve_batch_static"):
+        lib.mpcx_solve_batch_static.argtypes = [C.POINTER(MpcxBatch), C.POINTER(MpcxOpts),
+                                                C.POINTER(MpcxResult), C.c_void_p]
+        lib.mpcx_solve_batch_static.restype = C.c_int
     if path is None:
         _lib = lib
     return lib
@@ -113,14 +129,18 @@ def alloc_result(B, N):
 
 
 def batch_struct(packed):
+    """mpcx_batch over the host arrays of a PackedBatch (xguess None = NULL: the library's guess)."""
     assert packed.pdata.flags.c_contiguous and packed.pdata.dtype == np.float64
-    assert packed.xguess.flags.c_contiguous and packed.xguess.dtype == np.float64
+    assert packed.pdata.shape == (MPCX_NFIELDS, packed.B)
     assert packed.n_obs.flags.c_contiguous and packed.n_obs.dtype == np.int32
+    xg = packed.xguess
+    if xg is not None:
+        assert xg.flags.c_contiguous and xg.dtype == np.float64 and xg.shape == (packed.N + 1, 5, packed.B)
     ug = getattr(packed, "uguess", None)
     if ug is not None:
         assert ug.flags.c_contiguous and ug.dtype == np.float64 and ug.shape == (packed.N, 2, packed.B)
     return MpcxBatch(packed.B, packed.N, packed.pdata.ctypes.data,
-                     packed.n_obs.ctypes.data, packed.xguess.ctypes.data,
+                     packed.n_obs.ctypes.data, xg.ctypes.data if xg is not None else None,
                      ug.ctypes.data if ug is not None else None)
 
 
@@ -145,16 +165,69 @@ def solve_packed(packed, opts=None, device=0):
     return out
 
 
+class Context:
+    """Solver handle (mpcx_ctx): device buffers, workspace and page-locked result arrays kept from
+    call to call.  ``solve`` returns the output dict as numpy VIEWS of the handle's result arrays:
+    valid until the next ``solve`` / ``close`` on this handle (copy what must outlive that)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        if self.lib.mpcx_device_count() <= 0:
+            raise MpcxError("no HIP device available (there is no CPU fallback)")
+        self._h = C.c_void_p()
+        _check(self.lib, self.lib.mpcx_ctx_create(C.byref(self._h), int(device)), "mpcx_ctx_create")
+        self.stats = np.zeros(MPCX_NSTATS, dtype=np.int64)
+
+    def solve(self, packed, opts=None):
+        opts = opts or default_opts(self.lib)
+        b = batch_struct(packed)
+        r = MpcxResult()
+        _check(self.lib, self.lib.mpcx_ctx_solve(self._h, C.byref(b), C.byref(opts), C.byref(r),
+                                                 self.stats.ctypes.data), "mpcx_ctx_solve")
+        B, N = packed.B, packed.N
+
+        def view(ptr, ctype, shape):
+            n = int(np.prod(shape))
+            if n == 0:
+                return np.empty(shape, dtype=np.dtype(ctype))
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).reshape(shape)
+        return {"X": view(r.X, C.c_double, (B, N + 1, 5)), "U": view(r.U, C.c_double, (B, N, 2)),
+                "status": view(r.status, C.c_int32, (B,)), "sqp_iter": view(r.sqp_iter, C.c_int32, (B,)),
+                "qp_iter": view(r.qp_iter, C.c_int32, (B,)), "cost": view(r.cost, C.c_double, (B,)),
+                "res": view(r.res, C.c_double, (4, B))}
+
+    def close(self):
+        if self._h:
+            self.lib.mpcx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def initial_guess_on_device(pdata, width, N, device=0):
     """xguess [N+1, 5, B] of obstacle-free problems computed on HIP device ``device`` from the
-    problem table (host arrays in, host array out); bit-identical to batch.initial_guess_batch."""
+    problem table (host arrays in, host array out); bit-identical to batch.initial_guess_batch.
+    width None = the table's own corridor-width column."""
     lib = load_library()
     if lib.mpcx_device_count() <= 0:
         raise MpcxError("no HIP device available (there is no CPU fallback)")
     pdata = np.ascontiguousarray(pdata, dtype=np.float64)
-    width = np.ascontiguousarray(width, dtype=np.float64)
+    if width is not None:
+        width = np.ascontiguousarray(width, dtype=np.float64)
     B = pdata.shape[1]
     out = np.empty((N + 1, 5, B), dtype=np.float64)
-    _check(lib, lib.mpcx_initial_guess(pdata.ctypes.data, width.ctypes.data, B, N, out.ctypes.data, int(device)),
+    _check(lib, lib.mpcx_initial_guess(pdata.ctypes.data, width.ctypes.data if width is not None else None,
+                                       B, N, out.ctypes.data, int(device)),
            "mpcx_initial_guess")
     return out

@@ -21,8 +21,8 @@ MAX_OBS = 4
 # field offsets of include/mpcx.h (enum MPCX_F_*)
 F_X0, F_GOAL, F_W, F_WE = 0, 5, 10, 17
 F_LBU, F_UBU, F_LBX, F_UBX, F_LBXE, F_UBXE = 22, 24, 26, 31, 36, 41
-F_CG, F_LG, F_UG, F_L, F_H, F_LH, F_UH, F_OBS = 46, 50, 52, 54, 55, 56, 57, 58
-NFIELDS = 70
+F_CG, F_LG, F_UG, F_L, F_H, F_LH, F_UH, F_OBS, F_CW = 46, 50, 52, 54, 55, 56, 57, 58, 70
+NFIELDS = 71
 
 # constants the reference hard-codes in generate_controls
 EPS_POS, EPS_ANGLE, EPS_VEL = 1e-1, 1e-2, 1e-2      # core_solver.py:257-259
@@ -43,17 +43,32 @@ class PackedBatch:
     N: int
     pdata: np.ndarray    # float64 [NFIELDS, B]
     n_obs: np.ndarray    # int32 [B]
-    xguess: np.ndarray   # float64 [N+1, 5, B]
+    xguess: np.ndarray   # float64 [N+1, 5, B], or None = the library computes the guess on the
+                         # device from the problem table (obstacle-free problems only)
     duration: float = 0.0
     uguess: np.ndarray = None    # float64 [N, 2, B] or None = zeros (the reference's start)
 
+    def guess(self):
+        """The state guess as a host array [N+1, 5, B]: the packed one, or, where the batch leaves
+        it to the device, the host loop on the same table (identical to the device's, bit for bit)."""
+        if self.xguess is not None:
+            return self.xguess
+        if self.B and int(self.n_obs.max()) > 0:
+            raise ValueError("a batch with obstacles carries its guess (core_solver.py:360-473 runs on the host)")
+        pd = self.pdata
+        return initial_guess_batch(pd[F_X0:F_X0 + 5].T, pd[F_GOAL:F_GOAL + 5].T, pd[F_CW], self.N,
+                                   pd[F_CG + 2], pd[F_UG], -pd[F_UG + 1])
+
+    def take(self, idx):
+        """The problems ``idx`` (an index array or a slice) as a batch of their own."""
+        pick = lambda a, ax: None if a is None else np.ascontiguousarray(
+            a[(slice(None),) * ax + (idx,)])
+        n_obs = pick(self.n_obs, 0)
+        return PackedBatch(int(n_obs.shape[0]), self.N, pick(self.pdata, 1), n_obs,
+                           pick(self.xguess, 2), self.duration, pick(self.uguess, 2))
+
     def slice(self, lo, hi):
-        return PackedBatch(hi - lo, self.N,
-                           np.ascontiguousarray(self.pdata[:, lo:hi]),
-                           np.ascontiguousarray(self.n_obs[lo:hi]),
-                           np.ascontiguousarray(self.xguess[:, :, lo:hi]),
-                           self.duration,
-                           None if self.uguess is None else np.ascontiguousarray(self.uguess[:, :, lo:hi]))
+        return self.take(slice(lo, hi))
 
 
 # ---------------------------------------------------------------------------
@@ -259,6 +274,7 @@ def _ego_fields(ego, N, duration):
     col[F_H] = duration / N
     col[F_LH] = H_LOWER
     col[F_UH] = H_UPPER
+    col[F_CW] = ego.corridor_width
     n_obs = 0
     if ego.obstacles is not None and len(ego.obstacles) > 0:
         n_obs = len(ego.obstacles)
@@ -269,28 +285,47 @@ def _ego_fields(ego, N, duration):
     return col, n_obs, corridor
 
 
-def pack_problems(egos, sim_cfg):
-    """Pack EgoConfig objects that share one SimConfig into a PackedBatch."""
+def pack_problems(egos, sim_cfg, errors=None, device_guess=False):
+    """Pack EgoConfig objects that share one SimConfig into a PackedBatch.
+
+    errors: None = an ego that cannot be packed (coincident start and goal, more than four
+    obstacles, a state of the wrong length ...) raises.  A dict = such egos are left out of the
+    batch, ``errors[i]`` receives the exception of ego i, and the batch holds the others in
+    their order (the reference isolates failures per problem, core_solver.py:540-562).
+    device_guess: leave the state guess of an obstacle-free batch to the library (xguess None).
+    """
     N = horizon_length(sim_cfg)
     if N < 1:
         raise ValueError("duration / dt must give at least one shooting interval")
-    B = len(egos)
+    cols, counts, corridors, kept = [], [], [], []
+    for i, ego in enumerate(egos):
+        try:
+            col, nb, corridor = _ego_fields(ego, N, sim_cfg.duration)
+        except Exception as e:
+            if errors is None:
+                raise
+            errors[i] = e
+            continue
+        cols.append(col)
+        counts.append(nb)
+        corridors.append(corridor)
+        kept.append(i)
+    B = len(kept)
     pdata = np.zeros((NFIELDS, B), dtype=np.float64)
-    n_obs = np.zeros(B, dtype=np.int32)
+    if B:
+        pdata[:, :] = np.array(cols).T
+    n_obs = np.array(counts, dtype=np.int32).reshape(B)
+    if device_guess and (B == 0 or int(n_obs.max()) == 0):
+        return PackedBatch(B, N, pdata, n_obs, None, float(sim_cfg.duration))
     xguess = np.empty((N + 1, NX, B), dtype=np.float64)
-    width = np.empty(B, dtype=np.float64)
-    for b, ego in enumerate(egos):
-        col, nb, corridor = _ego_fields(ego, N, sim_cfg.duration)
-        pdata[:, b] = col
-        n_obs[b] = nb
-        width[b] = ego.corridor_width
-        if nb > 0:      # the obstacle branch of the guess is a scalar loop
-            xguess[:, :, b] = initial_guess(ego, N, corridor)
+    for b, i in enumerate(kept):
+        if n_obs[b] > 0:      # the obstacle branch of the guess is a scalar loop
+            xguess[:, :, b] = initial_guess(egos[i], N, corridors[b])
     free = np.nonzero(n_obs == 0)[0]
     if free.size:
         # obstacle-free problems: the same operations, all problems at once
         xguess[:, :, free] = initial_guess_batch(
-            pdata[F_X0:F_X0 + 5, free].T, pdata[F_GOAL:F_GOAL + 5, free].T, width[free], N,
+            pdata[F_X0:F_X0 + 5, free].T, pdata[F_GOAL:F_GOAL + 5, free].T, pdata[F_CW, free], N,
             pdata[F_CG + 2, free], pdata[F_UG, free], -pdata[F_UG + 1, free])
     return PackedBatch(B, N, pdata, n_obs, xguess, float(sim_cfg.duration))
 
@@ -303,10 +338,11 @@ def normalize_angle_array(angle):
 def pack_arrays(start, goal, duration, dt=0.1, corridor_width=15.0, L=2.7,
                 velocity=(-3.0, 3.0), acceleration=(-2.0, 2.0), steering=(-0.5, 0.5),
                 steering_rate=(-0.4, 0.4), weights=(100.0, 100.0, 0.0, 0.0, 0.0, 0.0, 0.0),
-                terminal_weights=(100.0, 100.0, 100.0, 10.0, 10.0), obstacle=None):
+                terminal_weights=(100.0, 100.0, 100.0, 10.0, 10.0), obstacle=None, device_guess=False):
     """Vectorised packing of problems that differ only in start and goal state
     (the synthetic benchmark batch, the grid sweep) and, optionally, in the one
     obstacle each has (obstacle: [B, 4] rows x, y, radius, margin).
+    device_guess: leave the state guess of an obstacle-free batch to the library (xguess None).
 
     start, goal: [B, 5]; headings are wrapped exactly as the EgoConfig setters
     wrap them.  Every other EgoConfig field takes the given common value
@@ -345,6 +381,7 @@ def pack_arrays(start, goal, duration, dt=0.1, corridor_width=15.0, L=2.7,
     pdata[F_H] = duration / N
     pdata[F_LH] = H_LOWER
     pdata[F_UH] = H_UPPER
+    pdata[F_CW] = width
     n_obs = np.zeros(B, dtype=np.int32)
     if obstacle is not None:
         obstacle = np.asarray(obstacle, dtype=np.float64)
@@ -352,5 +389,7 @@ def pack_arrays(start, goal, duration, dt=0.1, corridor_width=15.0, L=2.7,
         pdata[F_OBS + 1] = obstacle[:, 1]
         pdata[F_OBS + 2] = (obstacle[:, 2] + obstacle[:, 3])**2
         n_obs[:] = 1
+    if device_guess and obstacle is None:
+        return PackedBatch(B, N, pdata, n_obs, None, float(duration))
     xguess = initial_guess_batch(start, goal, width, N, a, b1, b2, obstacle)
     return PackedBatch(B, N, pdata, n_obs, xguess, float(duration))

@@ -112,7 +112,7 @@ def _result_dict(out, b, N, duration):
     }
 
 
-def solve_groups(egos, sim_cfgs, opts=None, device=0, solver=None):
+def solve_groups(egos, sim_cfgs, opts=None, device=0, solver=None, errors=None):
     """Solve many problems; returns ``(status, sqp_iter, qp_iter, results)``.
 
     Problems are grouped by horizon length N (one library call per distinct N,
@@ -120,36 +120,61 @@ def solve_groups(egos, sim_cfgs, opts=None, device=0, solver=None):
     ``results[i]`` is the reference's result dict whatever the status.
     ``solver`` replaces the HIP call with a callable of the same signature
     as ``_lib.solve_packed`` (tests use it to run the CPU oracle).
+    ``errors``: None = a problem that cannot be set up raises (as one call of the
+    reference's generate_controls would); a dict = such a problem is left out,
+    ``errors[i]`` receives its exception, ``results[i]`` stays None and
+    ``status[i]`` is -1, and every other problem is solved.
     """
+    device_guess = solver is None       # the HIP library computes the guess of obstacle-free batches itself
     solver = solver or _lib.solve_packed
     n = len(egos)
     if not isinstance(sim_cfgs, (list, tuple)):
         sim_cfgs = [sim_cfgs] * n
     groups = {}
     for i, sc in enumerate(sim_cfgs):
-        groups.setdefault((horizon_length(sc), float(sc.duration)), []).append(i)
+        try:
+            key = (horizon_length(sc), float(sc.duration))
+            if key[0] < 1:
+                raise ValueError("duration / dt must give at least one shooting interval")
+        except Exception as e:
+            if errors is None:
+                raise
+            errors[i] = e
+            continue
+        groups.setdefault(key, []).append(i)
     status = np.zeros(n, dtype=np.int32)
     sqp_iter = np.zeros(n, dtype=np.int32)
     qp_iter = np.zeros(n, dtype=np.int32)
     results = [None] * n
     for (N, duration), idx in groups.items():
-        packed = pack_problems([egos[i] for i in idx], sim_cfgs[idx[0]])
+        bad = None if errors is None else {}
+        packed = pack_problems([egos[i] for i in idx], sim_cfgs[idx[0]], errors=bad, device_guess=device_guess)
+        if bad:
+            for j, e in bad.items():
+                errors[idx[j]] = e
+            idx = [i for j, i in enumerate(idx) if j not in bad]
         out = solver(packed, opts, device)
         for j, i in enumerate(idx):
             status[i] = out["status"][j]
             sqp_iter[i] = out["sqp_iter"][j]
             qp_iter[i] = out["qp_iter"][j]
             results[i] = _result_dict(out, j, N, duration)
+    if errors:
+        for i in errors:
+            status[i] = -1
     return status, sqp_iter, qp_iter, results
 
 
-def generate_controls_batch(egos, sim_cfgs, opts=None, device=0, solver=None):
+def generate_controls_batch(egos, sim_cfgs, opts=None, device=0, solver=None, errors=None):
     """Batched ``generate_controls``: list of result dicts, ``None`` where the
-    solver status is non-zero (with the reference's printed line, :505-507)."""
-    status, _, _, results = solve_groups(egos, sim_cfgs, opts, device, solver)
+    solver status is non-zero (with the reference's printed line, :505-507).
+    ``errors`` as in ``solve_groups`` (no line is printed for a problem listed there)."""
+    status, _, _, results = solve_groups(egos, sim_cfgs, opts, device, solver, errors)
     out = []
-    for s, r in zip(status, results):
-        if s != 0:
+    for i, (s, r) in enumerate(zip(status, results)):
+        if errors and i in errors:
+            out.append(None)
+        elif s != 0:
             print(f"Solver failed with status {int(s)}")
             out.append(None)
         else:
@@ -165,25 +190,33 @@ def generate_controls(ego, sim_cfg, opts=None, device=0, solver=None):
 def find_paths(egos, sim_cfgs, opts=None, device=0, solver=None):
     """Batched ``find_path``: never raises; ``None`` for every failed problem.
 
-    Output of the solve is silenced unless some ``ego.verbose`` is true; the
-    per-problem success / failure lines follow each problem's own flag.
+    A problem that cannot be set up fails alone, as in the reference's loop of
+    ``find_path`` calls (core_solver.py:540-562, grid_path_plan.py:78-89): the
+    others are still solved.  Only a failure of the solve call itself (no
+    device, library missing) fails the whole batch.  Output of the solve is
+    silenced unless some ``ego.verbose`` is true; the per-problem success /
+    failure lines follow each problem's own flag.
     """
     n = len(egos)
+    errors = {}
     try:
         if any(e.verbose for e in egos):
-            res = generate_controls_batch(egos, sim_cfgs, opts, device, solver)
+            res = generate_controls_batch(egos, sim_cfgs, opts, device, solver, errors)
         else:
             with _Silence():
-                res = generate_controls_batch(egos, sim_cfgs, opts, device, solver)
+                res = generate_controls_batch(egos, sim_cfgs, opts, device, solver, errors)
     except Exception as e:                              # reference :559-562
         for ego in egos:
             if ego.verbose:
                 print(f"✗ Error during path planning: {str(e)}")
         return [None] * n
-    for ego, r in zip(egos, res):
+    for i, (ego, r) in enumerate(zip(egos, res)):
         if ego.verbose:
-            print("✓ Path planning successful" if r is not None
-                  else "✗ Error during path planning: 'NoneType' object is not subscriptable")
+            if i in errors:
+                print(f"✗ Error during path planning: {str(errors[i])}")
+            else:
+                print("✓ Path planning successful" if r is not None
+                      else "✗ Error during path planning: 'NoneType' object is not subscriptable")
     return res
 
 

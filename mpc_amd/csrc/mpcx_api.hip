@@ -8,14 +8,22 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
-#include <vector>
+#include <new>
 
 #include "../../include/mpcx.h"
 #include "mpcx_kernels.h"
 
+// Workspace of mpcx_solve_batch_static: one copy per GPU the library is loaded on, held until the
+// process ends.  Host code never passes this name to a kernel; it passes the address that
+// hipGetSymbolAddress returns for the current device.
+static __device__ __align__(256) unsigned char scratch[MPCX_STATIC_SCRATCH_BYTES];
+
 namespace {
 
+constexpr int kMaxDevices = 64;
+std::atomic<void *> g_scratch_ptr[kMaxDevices];
 
 thread_local char g_err[512] = "";
 
@@ -63,6 +71,17 @@ size_t default_workspace_target()
 size_t wave_bytes(int N, int nh)
 {
     return (size_t)((N + 1) + kSlots * ((N + 64) / 64)) * mpcx_stage_doubles(nh) * 64 * sizeof(double);
+}
+
+// largest N whose wavefront workspace stays below the 4 GiB that 32-bit byte offsets reach
+int mpcx_max_horizon_impl()
+{
+    int lo = 1, hi = 1 << 20;
+    while (lo < hi) {
+        const int mid = lo + (hi - lo + 1) / 2;
+        if (wave_bytes(mid, MPCX_MAX_OBS) < ((size_t)1 << 32)) lo = mid; else hi = mid - 1;
+    }
+    return lo;
 }
 
 Plan plan_for(int B, int N, size_t target, bool rti = false)
@@ -122,7 +141,10 @@ int check_call(const mpcx_batch *in, const mpcx_opts *o, const mpcx_result *out)
 {
     if (!in || !o || !out) return fail(MPCX_E_BADARG, "null argument");
     if (in->B < 0 || in->N < 1) return fail(MPCX_E_BADARG, "need B >= 0 and N >= 1 (B=%d, N=%d)", in->B, in->N);
-    if (in->B > 0 && (!in->pdata || !in->xguess)) return fail(MPCX_E_BADARG, "null pdata / xguess");
+    if (in->B > 0 && !in->pdata) return fail(MPCX_E_BADARG, "null pdata");
+    // the kernels address a wavefront's workspace with 32-bit byte offsets
+    if (wave_bytes(in->N, MPCX_MAX_OBS) >= ((size_t)1 << 32))
+        return fail(MPCX_E_BADARG, "N = %d too large: a wavefront's workspace would reach 4 GiB (N <= %d)", in->N, mpcx_max_horizon());
     if (in->B > 0 && (!out->X || !out->U || !out->status || !out->sqp_iter || !out->qp_iter ||
                       !out->cost || !out->res))
         return fail(MPCX_E_BADARG, "null output array");
@@ -138,6 +160,41 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+
+// a buffer that grows on demand and is kept between calls: device memory, or page-locked host memory
+struct Grow {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool host = false;
+    void release()
+    {
+        if (p) (void)(host ? hipHostFree(p) : hipFree(p));
+        p = nullptr;
+        cap = 0;
+    }
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        release();
+        const hipError_t e = host ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = bytes;
+        return hipSuccess;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+}  // namespace
+
+struct mpcx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Grow pd, no, xg, ug, X, U, st, si, qi, co, re, ws, stats;      // device
+    Grow hX, hU, hst, hsi, hqi, hco, hre, hstats;                  // page-locked host
+    mpcx_ctx() { hX.host = hU.host = hst.host = hsi.host = hqi.host = hco.host = hre.host = hstats.host = true; }
+};
+
+namespace {
 }  // namespace
 
 extern "C" {
@@ -164,6 +221,12 @@ void mpcx_opts_default(mpcx_opts *o)
     o->t_min = 1e-16;
     o->rti = 0;
     o->max_obs = -1;
+}
+
+int mpcx_max_horizon(void)
+{
+    static const int n = mpcx_max_horizon_impl();
+    return n;
 }
 
 int mpcx_device_count(void)
@@ -219,8 +282,10 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     }
     if (o.max_obs >= 0 && o.max_obs < nh) return fail(MPCX_E_BADARG, "max_obs %d < largest n_obs %d", o.max_obs, nh);
     o.max_obs = nh;
+    if (!in->xguess && nh > 0)
+        return fail(MPCX_E_BADARG, "xguess is NULL but the batch has obstacles: their guess (core_solver.py:360-473) is the caller's");
 
-    const size_t n_pd = (size_t)MPCX_NFIELDS * B, n_xg = (N + 1) * MPCX_NX * B;
+    const size_t n_pd = (size_t)MPCX_NFIELDS * B, n_xg = in->xguess ? (N + 1) * MPCX_NX * B : 0;
     const size_t n_X = B * (N + 1) * MPCX_NX, n_U = B * N * MPCX_NU;
     // the widest spread whose workspace can be allocated
     DevBuf d_ws;
@@ -248,7 +313,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     HIP_TRY(hipMemcpy(d_pd.p, in->pdata, n_pd * 8, hipMemcpyHostToDevice));
     if (in->n_obs) HIP_TRY(hipMemcpy(d_no.p, in->n_obs, B * 4, hipMemcpyHostToDevice));
     else HIP_TRY(hipMemset(d_no.p, 0, B * 4));
-    HIP_TRY(hipMemcpy(d_xg.p, in->xguess, n_xg * 8, hipMemcpyHostToDevice));
+    if (in->xguess) HIP_TRY(hipMemcpy(d_xg.p, in->xguess, n_xg * 8, hipMemcpyHostToDevice));
     if (in->uguess) {
         if (d_ug.alloc(n_U * 8) != hipSuccess) { (void)hipGetLastError(); return fail(MPCX_E_NOMEM, "device allocation failed"); }
         HIP_TRY(hipMemcpy(d_ug.p, in->uguess, n_U * 8, hipMemcpyHostToDevice));
@@ -258,7 +323,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     mpcx_batch din = *in;
     din.pdata = d_pd.as<double>();
     din.n_obs = d_no.as<int32_t>();
-    din.xguess = d_xg.as<double>();
+    din.xguess = in->xguess ? d_xg.as<double>() : nullptr;
     din.uguess = in->uguess ? d_ug.as<double>() : nullptr;
     mpcx_result dout;
     dout.X = d_X.as<double>();
@@ -282,14 +347,12 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     return 0;
 }
 
-// arithmetic probe used by the parity tests: sin/cos of n host doubles as the
-// solver computes them on the device
 int mpcx_initial_guess_device(const double *pdata, const double *width, int32_t B, int32_t N,
                               double *xguess, void *stream)
 {
     if (B < 0 || N < 1) return fail(MPCX_E_BADARG, "need B >= 0 and N >= 1 (B=%d, N=%d)", B, N);
     if (B == 0) return 0;
-    if (!pdata || !width || !xguess) return fail(MPCX_E_BADARG, "null argument");
+    if (!pdata || !xguess) return fail(MPCX_E_BADARG, "null argument");
     if (mpcx_device_count() <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
     HIP_TRY(mpcx_launch_guess(pdata, width, B, N, xguess, static_cast<hipStream_t>(stream)));
     return 0;
@@ -300,7 +363,7 @@ int mpcx_initial_guess(const double *pdata, const double *width, int32_t B, int3
 {
     if (B < 0 || N < 1) return fail(MPCX_E_BADARG, "need B >= 0 and N >= 1 (B=%d, N=%d)", B, N);
     if (B == 0) return 0;
-    if (!pdata || !width || !xguess) return fail(MPCX_E_BADARG, "null argument");
+    if (!pdata || !xguess) return fail(MPCX_E_BADARG, "null argument");
     const int ndev = mpcx_device_count();
     if (ndev <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
     if (device < 0 || device >= ndev) return fail(MPCX_E_BADARG, "device %d out of range [0, %d)", device, ndev);
@@ -313,8 +376,8 @@ int mpcx_initial_guess(const double *pdata, const double *width, int32_t B, int3
         return fail(MPCX_E_NOMEM, "device allocation failed");
     }
     HIP_TRY(hipMemcpy(d_pd.p, pdata, n_pd * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_w.p, width, (size_t)B * 8, hipMemcpyHostToDevice));
-    HIP_TRY(mpcx_launch_guess(d_pd.as<double>(), d_w.as<double>(), B, N, d_xg.as<double>(), nullptr));
+    if (width) HIP_TRY(hipMemcpy(d_w.p, width, (size_t)B * 8, hipMemcpyHostToDevice));
+    HIP_TRY(mpcx_launch_guess(d_pd.as<double>(), width ? d_w.as<double>() : nullptr, B, N, d_xg.as<double>(), nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(xguess, d_xg.p, n_xg * 8, hipMemcpyDeviceToHost));
     return 0;
@@ -336,11 +399,174 @@ int mpcx_batch_stats_device(const int32_t *status, const int32_t *sqp_iter, cons
     return 0;
 }
 
+int mpcx_ctx_create(mpcx_ctx **ctx, int device)
+{
+    if (!ctx) return fail(MPCX_E_BADARG, "null argument");
+    *ctx = nullptr;
+    const int ndev = mpcx_device_count();
+    if (ndev <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(MPCX_E_BADARG, "device %d out of range [0, %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    mpcx_ctx *c = new (std::nothrow) mpcx_ctx;
+    if (!c) return fail(MPCX_E_NOMEM, "out of host memory");
+    c->device = device;
+    const hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(MPCX_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *ctx = c;
+    return 0;
+}
+
+void mpcx_ctx_destroy(mpcx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    Grow *all[] = {&c->pd, &c->no, &c->xg, &c->ug, &c->X, &c->U, &c->st, &c->si, &c->qi, &c->co, &c->re, &c->ws,
+                   &c->stats, &c->hX, &c->hU, &c->hst, &c->hsi, &c->hqi, &c->hco, &c->hre, &c->hstats};
+    for (Grow *g : all) g->release();
+    delete c;
+}
+
+int mpcx_ctx_solve(mpcx_ctx *c, const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *out, int64_t *stats)
+{
+    if (!c || !in || !opts || !out) return fail(MPCX_E_BADARG, "null argument");
+    if (in->B < 0 || in->N < 1) return fail(MPCX_E_BADARG, "need B >= 0 and N >= 1 (B=%d, N=%d)", in->B, in->N);
+    if (in->B > 0 && !in->pdata) return fail(MPCX_E_BADARG, "null pdata");
+    if (wave_bytes(in->N, MPCX_MAX_OBS) >= ((size_t)1 << 32))
+        return fail(MPCX_E_BADARG, "N = %d too large: a wavefront's workspace would reach 4 GiB (N <= %d)", in->N, mpcx_max_horizon());
+    if (opts->max_sqp_iter < 0 || opts->max_qp_iter < 0) return fail(MPCX_E_BADARG, "negative iteration limit");
+    if (opts->max_obs > MPCX_MAX_OBS) return fail(MPCX_E_BADARG, "max_obs %d > %d", opts->max_obs, MPCX_MAX_OBS);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t B = (size_t)in->B, N = (size_t)in->N;
+    mpcx_opts o = *opts;
+    int nh = 0;
+    if (in->n_obs) {
+        for (size_t b = 0; b < B; ++b) {
+            if (in->n_obs[b] < 0 || in->n_obs[b] > MPCX_MAX_OBS)
+                return fail(MPCX_E_BADARG, "n_obs[%zu] = %d outside [0, %d]", b, in->n_obs[b], MPCX_MAX_OBS);
+            if (in->n_obs[b] > nh) nh = in->n_obs[b];
+        }
+    }
+    if (o.max_obs >= 0 && o.max_obs < nh) return fail(MPCX_E_BADARG, "max_obs %d < largest n_obs %d", o.max_obs, nh);
+    o.max_obs = nh;
+    if (!in->xguess && nh > 0)
+        return fail(MPCX_E_BADARG, "xguess is NULL but the batch has obstacles: their guess (core_solver.py:360-473) is the caller's");
+
+    const size_t n_pd = (size_t)MPCX_NFIELDS * B, n_xg = in->xguess ? (N + 1) * MPCX_NX * B : 0;
+    const size_t n_X = B * (N + 1) * MPCX_NX, n_U = B * N * MPCX_NU;
+    // buffers: kept from the last call where large enough (at least one byte each, so B = 0 yields valid pointers)
+    struct { Grow *g; size_t bytes; } need[] = {
+        {&c->pd, n_pd * 8}, {&c->no, B * 4}, {&c->xg, n_xg * 8}, {&c->ug, in->uguess ? n_U * 8 : 0},
+        {&c->X, n_X * 8}, {&c->U, n_U * 8}, {&c->st, B * 4}, {&c->si, B * 4}, {&c->qi, B * 4}, {&c->co, B * 8},
+        {&c->re, 4 * B * 8}, {&c->stats, MPCX_NSTATS * 8},
+        {&c->hX, n_X * 8}, {&c->hU, n_U * 8}, {&c->hst, B * 4}, {&c->hsi, B * 4}, {&c->hqi, B * 4}, {&c->hco, B * 8},
+        {&c->hre, 4 * B * 8}, {&c->hstats, MPCX_NSTATS * 8}};
+    for (auto &n : need) {
+        if (n.g->ensure(n.bytes ? n.bytes : 1) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(MPCX_E_NOMEM, "allocation of %zu bytes failed", n.bytes);
+        }
+    }
+    out->X = c->hX.as<double>();
+    out->U = c->hU.as<double>();
+    out->status = c->hst.as<int32_t>();
+    out->sqp_iter = c->hsi.as<int32_t>();
+    out->qp_iter = c->hqi.as<int32_t>();
+    out->cost = c->hco.as<double>();
+    out->res = c->hre.as<double>();
+    if (B == 0) {
+        if (stats) std::memset(stats, 0, MPCX_NSTATS * sizeof(int64_t));
+        return 0;
+    }
+    // the widest spread whose workspace is there already or can be allocated
+    Plan plan;
+    size_t ws_bytes = 0;
+    for (size_t target = default_workspace_target();; target /= 2) {
+        plan = plan_for(in->B, in->N, target, o.rti != 0);
+        ws_bytes = 512 + (size_t)plan.waves * wave_bytes(in->N, nh);
+        if (c->ws.ensure(ws_bytes) == hipSuccess) break;
+        (void)hipGetLastError();
+        if (plan.waves == 1 || target < ((size_t)1 << 28))
+            return fail(MPCX_E_NOMEM, "device allocation failed (workspace %zu bytes)", ws_bytes);
+    }
+    hipStream_t q = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->pd.p, in->pdata, n_pd * 8, hipMemcpyHostToDevice, q));
+    if (in->n_obs) HIP_TRY(hipMemcpyAsync(c->no.p, in->n_obs, B * 4, hipMemcpyHostToDevice, q));
+    else HIP_TRY(hipMemsetAsync(c->no.p, 0, B * 4, q));
+    if (in->xguess) HIP_TRY(hipMemcpyAsync(c->xg.p, in->xguess, n_xg * 8, hipMemcpyHostToDevice, q));
+    if (in->uguess) HIP_TRY(hipMemcpyAsync(c->ug.p, in->uguess, n_U * 8, hipMemcpyHostToDevice, q));
+    HIP_TRY(hipMemsetAsync(c->st.p, 0xff, B * 4, q));
+    mpcx_batch din = *in;
+    din.pdata = c->pd.as<double>();
+    din.n_obs = c->no.as<int32_t>();
+    din.xguess = in->xguess ? c->xg.as<double>() : nullptr;
+    din.uguess = in->uguess ? c->ug.as<double>() : nullptr;
+    mpcx_result dout;
+    dout.X = c->X.as<double>();
+    dout.U = c->U.as<double>();
+    dout.status = c->st.as<int32_t>();
+    dout.sqp_iter = c->si.as<int32_t>();
+    dout.qp_iter = c->qi.as<int32_t>();
+    dout.cost = c->co.as<double>();
+    dout.res = c->re.as<double>();
+    HIP_TRY(mpcx_launch_sqp(nh, din, o, dout, c->ws.as<double>(), waves_to_launch(plan), plan.lanes, plan.coop_max,
+                            plan.lin_max, plan.coop_layout, kSlots, q));
+    HIP_TRY(mpcx_launch_stats(dout.status, dout.sqp_iter, dout.qp_iter, in->B, c->stats.as<long long>(), q));
+    HIP_TRY(hipMemcpyAsync(out->X, dout.X, n_X * 8, hipMemcpyDeviceToHost, q));
+    HIP_TRY(hipMemcpyAsync(out->U, dout.U, n_U * 8, hipMemcpyDeviceToHost, q));
+    HIP_TRY(hipMemcpyAsync(out->status, dout.status, B * 4, hipMemcpyDeviceToHost, q));
+    HIP_TRY(hipMemcpyAsync(out->sqp_iter, dout.sqp_iter, B * 4, hipMemcpyDeviceToHost, q));
+    HIP_TRY(hipMemcpyAsync(out->qp_iter, dout.qp_iter, B * 4, hipMemcpyDeviceToHost, q));
+    HIP_TRY(hipMemcpyAsync(out->cost, dout.cost, B * 8, hipMemcpyDeviceToHost, q));
+    HIP_TRY(hipMemcpyAsync(out->res, dout.res, 4 * B * 8, hipMemcpyDeviceToHost, q));
+    HIP_TRY(hipMemcpyAsync(c->hstats.p, c->stats.p, MPCX_NSTATS * 8, hipMemcpyDeviceToHost, q));
+    HIP_TRY(hipStreamSynchronize(q));
+    if (stats) std::memcpy(stats, c->hstats.p, MPCX_NSTATS * sizeof(int64_t));
+    return 0;
+}
+
+// The solve for callers that cannot allocate.  Its workspace is the file-scope device array below;
+// `scratch` names it on the host side only (a stand-in, not a device address): the address on each
+// device is looked up once, with that device current, and kept in g_scratch_ptr.
+int mpcx_solve_batch_static(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *out, void *stream)
+{
+    if (int rc = check_call(in, opts, out)) return rc;
+    if (in->B == 0) return 0;
+    if (mpcx_device_count() <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
+    const size_t least = 512 + wave_bytes(in->N, MPCX_MAX_OBS);
+    if (least > (size_t)MPCX_STATIC_SCRATCH_BYTES)
+        return fail(MPCX_E_BADARG, "N = %d needs %zu bytes of workspace, the built-in scratch holds %zu: use "
+                    "mpcx_solve_batch_device with a workspace of the caller's", in->N, least, (size_t)MPCX_STATIC_SCRATCH_BYTES);
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(MPCX_E_BADARG, "device %d outside [0, %d)", dev, kMaxDevices);
+    void *ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!ptr) {      // set-up, once per device: this device's copy of the array
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr || (uintptr_t)ptr % 256 != 0) return fail(MPCX_E_HIP, "scratch symbol lookup gave %p", ptr);
+        g_scratch_ptr[dev].store(ptr, std::memory_order_release);
+    }
+    const int nh = (opts->max_obs < 0) ? MPCX_MAX_OBS : opts->max_obs;
+    const Plan plan = plan_for(in->B, in->N, (size_t)MPCX_STATIC_SCRATCH_BYTES - 512, opts->rti != 0);
+    // (the launch zeroes the problem counter in the scratch header itself; everything else a solve
+    // reads of the workspace it has written before, so the last call's contents do not matter)
+    HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(ptr), waves_to_launch(plan), plan.lanes,
+                            plan.coop_max, plan.lin_max, plan.coop_layout, kSlots, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+// arithmetic probe used by the parity tests: sin/cos of n host doubles as the
+// solver computes them on the device
 int mpcx_probe_sincos(const double *x, int32_t n, double *s, double *c, int device)
 {
     if (!x || !s || !c || n < 0) return fail(MPCX_E_BADARG, "bad probe arguments");
     if (n == 0) return 0;
-    if (mpcx_device_count() <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
+    const int ndev = mpcx_device_count();
+    if (ndev <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(MPCX_E_BADARG, "device %d out of range [0, %d)", device, ndev);
     HIP_TRY(hipSetDevice(device));
     DevBuf dx, ds, dc;
     if (dx.alloc((size_t)n * 8) != hipSuccess || ds.alloc((size_t)n * 8) != hipSuccess ||

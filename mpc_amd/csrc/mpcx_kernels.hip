@@ -420,6 +420,50 @@ DEV void mul_AB(const Lane &L, const AB &ab, const double *dx, const double *du,
 }
 
 // ---------------------------------------------------------------------------
+// initial state guess of an obstacle-free problem at node i (reference core_solver.py:477-499):
+// the start-goal interpolation at t = i/N, y clamped to the reference's centre-line formula
+// +- width/2, heading interpolated, v = 1 - t, delta = 0; node N is the goal state.  The same
+// operations in the same order as the reference's loop, so a host program gets the same bits.
+// ---------------------------------------------------------------------------
+struct GuessData { double s[NX], g[NX], a, b1, b2, half; };
+
+// problem b's column of the table; width = the caller's column, or NULL = the table's own
+DEV void guess_data(const double *pdata, const double *width, size_t Bs, size_t b, GuessData &G)
+{
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        G.s[i] = pdata[(size_t)(MPCX_F_X0 + i) * Bs + b];
+        G.g[i] = pdata[(size_t)(MPCX_F_GOAL + i) * Bs + b];
+    }
+    // corridor rows are stored as (-a1, -c1, a2, c2) and (b1, -b2)
+    G.a = pdata[(size_t)(MPCX_F_CG + 2) * Bs + b];
+    G.b1 = pdata[(size_t)(MPCX_F_UG + 0) * Bs + b];
+    G.b2 = -pdata[(size_t)(MPCX_F_UG + 1) * Bs + b];
+    G.half = (width ? width[b] : pdata[(size_t)MPCX_F_CW * Bs + b]) / 2;
+}
+
+DEV void guess_node(const GuessData &G, int i, int N, double *o)
+{
+    if (i >= N) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) o[c] = G.g[c];
+        return;
+    }
+    const double t = (double)i / (double)N;
+    const double x = G.s[0] + t * (G.g[0] - G.s[0]);
+    double y = G.s[1] + t * (G.g[1] - G.s[1]);
+    const double yc = -(((G.a * x + G.b1 / 2) + G.a * x) + G.b2 / 2) / 2;
+    const double lo = yc - G.half, hi = yc + G.half;
+    y = (y > lo) ? y : lo;
+    y = (y < hi) ? y : hi;
+    o[0] = x;
+    o[1] = y;
+    o[2] = G.s[2] + t * (G.g[2] - G.s[2]);
+    o[3] = 1.0 * (1 - t);
+    o[4] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
 // rows of a stage.  r: 0-1 input box, 2-6 state box, 7-8 corridor, 9.. obstacles.
 // Stage 0 has the input rows only, stage N the state and corridor rows only,
 // the stages between have all of them (obstacle row j only if j < nobs).
@@ -2380,10 +2424,15 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                     L.b = b;
                     L.roff = 0;
                     int nobs = in.n_obs ? in.n_obs[b] : 0;
-                    if (nobs < 0 || nobs > NH) {     // the host validates; stay memory safe regardless
+                    // (the host validates both; stay memory safe, and never solve an obstacle problem from
+                    // the obstacle-free guess: the reference moves its guess off the obstacles, :360-473)
+                    if (nobs < 0 || nobs > NH || (nobs > 0 && !in.xguess)) {
                         out.status[b] = MPCX_NAN;
                         out.sqp_iter[b] = 0;
                         out.qp_iter[b] = 0;
+                        out.cost[b] = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) out.res[(size_t)i * L.B + b] = 0.0;
                     } else {
                         L.nobs = nobs;
                         L.h = ldp(L, MPCX_F_H);
@@ -2411,13 +2460,19 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                 const size_t b = (unsigned)__builtin_amdgcn_readlane((int)L.b, p);
                 Lane C;
                 problem_home(L, p, C);
+                GuessData G;
+                if (!in.xguess) guess_data(in.pdata, nullptr, L.B, b, G);      // no guess handed over: computed here
                 for (int k0 = 0; k0 <= N; k0 += 64) {
                     const int kj = k0 + (int)threadIdx.x;
                     if (kj > N) continue;
                     const Lane S = stage_lane(C, (unsigned)kj);
                     double xg[NX];
+                    if (in.xguess) {
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) xg[i] = in.xguess[((size_t)kj * NX + i) * L.B + b];
+                        for (int i = 0; i < NX; ++i) xg[i] = in.xguess[((size_t)kj * NX + i) * L.B + b];
+                    } else {
+                        guess_node(G, kj, N, xg);
+                    }
 #pragma unroll
                     for (int i = 0; i < NX; ++i) {
                         stw<ANY>(S, 0, M::X + i, xg[i]);
@@ -2595,6 +2650,13 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     }
 }
 
+// workspace header of a launch: problem counter (and the rest of its 256 bytes) zero, options behind it
+__global__ void mpcx_header_kernel(int *counter, mpcx_opts *d_opts, mpcx_opts o)
+{
+    counter[threadIdx.x] = 0;
+    if (threadIdx.x == 0) *d_opts = o;
+}
+
 // initial guess without obstacles (reference core_solver.py:477-499): one thread per problem,
 // node by node; every store of a wavefront is one contiguous segment of xguess[i][c][:]
 __global__ void mpcx_guess_kernel(const double *pdata, const double *width, int B, int N, double *xguess)
@@ -2602,37 +2664,16 @@ __global__ void mpcx_guess_kernel(const double *pdata, const double *width, int 
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const size_t Bs = (size_t)B;
-    double s[NX], g[NX];
+    GuessData G;
+    guess_data(pdata, width, Bs, (size_t)b, G);
+    for (int i = 0; i <= N; ++i) {
+        double o[NX];
+        guess_node(G, i, N, o);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        s[i] = pdata[(size_t)(MPCX_F_X0 + i) * Bs + b];
-        g[i] = pdata[(size_t)(MPCX_F_GOAL + i) * Bs + b];
+        for (int c = 0; c < NX; ++c) xguess[((size_t)i * NX + c) * Bs + b] = o[c];
     }
-    // corridor rows are stored as (-a1, -c1, a2, c2) and (b1, -b2)
-    const double a = pdata[(size_t)(MPCX_F_CG + 2) * Bs + b];
-    const double b1 = pdata[(size_t)(MPCX_F_UG + 0) * Bs + b];
-    const double b2 = -pdata[(size_t)(MPCX_F_UG + 1) * Bs + b];
-    const double half = width[b] / 2;
-    for (int i = 0; i < N; ++i) {
-        const double t = (double)i / (double)N;
-        const double x = s[0] + t * (g[0] - s[0]);
-        double y = s[1] + t * (g[1] - s[1]);
-        const double yc = -(((a * x + b1 / 2) + a * x) + b2 / 2) / 2;
-        const double lo = yc - half, hi = yc + half;
-        y = (y > lo) ? y : lo;
-        y = (y < hi) ? y : hi;
-        double *o = xguess + (size_t)i * NX * Bs + b;
-        o[0 * Bs] = x;
-        o[1 * Bs] = y;
-        o[2 * Bs] = s[2] + t * (g[2] - s[2]);
-        o[3 * Bs] = 1.0 * (1 - t);
-        o[4 * Bs] = 0.0;
-    }
-#pragma unroll
-    for (int c = 0; c < NX; ++c) xguess[((size_t)N * NX + c) * Bs + b] = g[c];
 }
 
-// sin/cos as the solver computes them, for the arithmetic parity tests
 // Outcome counters of a solved batch: stats[0..4] = problems per status 0..4, [5] = QP solves,
 // [6] = interior-point iterations, [7] = linearisations (one after every QP solve that did not
 // fail, plus the first).  One grid-stride pass, a shuffle reduction per wavefront, then one
@@ -2658,6 +2699,7 @@ __global__ void __launch_bounds__(256) mpcx_stats_kernel(const int32_t *status, 
     }
 }
 
+// sin/cos as the solver computes them, for the arithmetic parity tests
 __global__ void mpcx_probe_kernel(const double *xin, int n, double *s, double *c)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2700,10 +2742,9 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     int *counter = reinterpret_cast<int *>(workspace);
     mpcx_opts *d_opts = reinterpret_cast<mpcx_opts *>(reinterpret_cast<char *>(workspace) + 256);
     double *ws = workspace + 64;
-    hipError_t e = hipMemsetAsync(counter, 0, 256, stream);
-    if (e != hipSuccess) return e;
-    // the source is read when the copy is enqueued only if it is pageable host memory, which `o` is
-    e = hipMemcpyAsync(d_opts, &o, sizeof(mpcx_opts), hipMemcpyHostToDevice, stream);
+    // (the options travel as a kernel argument: no copy from host memory, nothing to stage)
+    hipLaunchKernelGGL(mpcx_header_kernel, dim3(1), dim3(64), 0, stream, counter, d_opts, o);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // fetch order inside the last (partial) block of 65536 problems: a multiplier coprime to its size
     // near the golden-section point; 0 = the caller's order throughout (MPCX_DEAL=0)

@@ -1,39 +1,59 @@
 """Algorithmic FP64 operation counts of the solve, per problem.
 
-The constants were frozen by running the CPU restatement built with an
-operation-counting scalar type (FMA = 2, + - * / = 1, sin and cos = 1 each)
-on the synthetic benchmark batch (no obstacles, default options):
-  F_LIN   per stage and linearisation: RK4 + sensitivities, cost and row
-          values, NLP residuals, iterate update, objective
-  F_INIT  per stage and QP solve: interior-point cold start + first residuals
-  F_IPM   per stage and interior-point iteration (mean over the batch: the
-          conditional third Riccati solve runs on part of the iterations)
-A structure-exploiting kernel executes fewer operations than this; the
-figure is the algorithm's, as the roofline convention asks.
+Two sets of per-stage constants (FMA = 2, + - * / = 1, sin and cos = 1 each):
+
+* structure-exploiting (the set the roofline fraction is quoted on): the closed forms for
+  nx = 5, nu = 2 -- interior-point iteration 1.5e3 = Riccati factorisation
+  7/3 nx^3 + 4 nx^2 nu + 2 nx nu^2 + nu^3/3 = 534, two substitutions (predictor, corrector)
+  2 (8 nx^2 + 8 nx nu + 2 nu^2) = 576, barrier Hessian / right-hand sides / step lengths /
+  residuals over the 18 row sides of a stage ~ 400; linearisation 1.1e3 = four RK4 stages with
+  sparse forward sensitivities, cost gradient and row values; NLP residuals and cold start 2e2
+  per QP solve;
+* dense count: what the CPU restatement executes, frozen by running it built with an
+  operation-counting scalar type on the synthetic benchmark batch (it multiplies by the
+  structural zeros and ones of the sensitivities and always substitutes three right-hand
+  sides); an upper bound of the algorithm's work, reported beside the other.
 """
 import numpy as np
 
-F_LIN = 1032.0
-F_INIT = 345.0
-F_IPM = 3325.0
+F_LIN, F_INIT, F_IPM = 1100.0, 200.0, 1500.0                       # structure-exploiting closed forms
+F_LIN_DENSE, F_INIT_DENSE, F_IPM_DENSE = 1032.0, 345.0, 3325.0    # counted on the dense restatement
 
 
-def algorithmic_flops(status, sqp_iter, qp_iter, N):
+def constants(sparse=True):
+    """The per-stage constants as a dict (for the benchmark line)."""
+    if sparse:
+        return {"per_stage_linearisation": F_LIN, "per_stage_qp_solve": F_INIT, "per_stage_ip_iteration": F_IPM,
+                "kind": "closed forms for nx=5, nu=2 exploiting the sparsity of the sensitivities"}
+    return {"per_stage_linearisation": F_LIN_DENSE, "per_stage_qp_solve": F_INIT_DENSE,
+            "per_stage_ip_iteration": F_IPM_DENSE, "kind": "counted on the dense CPU restatement"}
+
+
+def algorithmic_flops(status, sqp_iter, qp_iter, N, sparse=False):
     """Total flops over the problems of a batch, from their own counters."""
     status = np.asarray(status)
     sqp = np.asarray(sqp_iter, dtype=np.float64)
     qp = np.asarray(qp_iter, dtype=np.float64)
     # a QP failure (status 4) stops right after the QP; every other exit follows a linearisation
     n_lin = np.where(status == 4, sqp, sqp + 1.0)
-    return float(N * (F_LIN * n_lin.sum() + F_INIT * sqp.sum() + F_IPM * qp.sum()))
+    lin, init, ipm = (F_LIN, F_INIT, F_IPM) if sparse else (F_LIN_DENSE, F_INIT_DENSE, F_IPM_DENSE)
+    return float(N * (lin * n_lin.sum() + init * sqp.sum() + ipm * qp.sum()))
 
 
-def flops_from_stats(stats, N):
+def flops_from_stats(stats, N, sparse=False):
     """The same total from the device-side counters of mpcx_batch_stats_device
     (stats[5] = QP solves, [6] = interior-point iterations, [7] = linearisations)."""
-    return float(N * (F_LIN * float(stats[7]) + F_INIT * float(stats[5]) + F_IPM * float(stats[6])))
+    lin, init, ipm = (F_LIN, F_INIT, F_IPM) if sparse else (F_LIN_DENSE, F_INIT_DENSE, F_IPM_DENSE)
+    return float(N * (lin * float(stats[7]) + init * float(stats[5]) + ipm * float(stats[6])))
 
 
-# bytes the caller hands over and gets back per problem (N shooting intervals)
-def algorithmic_io_bytes(N):
-    return 8 * (70 + (N + 1) * 5) + 4 + 8 * ((N + 1) * 5 + N * 2) + 3 * 4 + 8 * 5
+def result_bytes(N):
+    """Bytes of one problem's results: X, U, status and two counters, cost, four residuals."""
+    return 8 * ((N + 1) * 5 + N * 2) + 3 * 4 + 8 * 5
+
+
+def algorithmic_io_bytes(N, host_guess=False):
+    """Bytes the caller hands over and gets back per problem (N shooting intervals): one column of
+    the problem table (71 doubles) and the obstacle count, the state guess if the host supplies
+    it, and the results."""
+    return 8 * 71 + 4 + (8 * (N + 1) * 5 if host_guess else 0) + result_bytes(N)

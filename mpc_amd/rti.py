@@ -14,6 +14,11 @@ Tick semantics, for vehicle b with horizon N and step h:
   3. shift:  xguess[k] = X[k+1] (k < N), xguess[N] = X[N];  xguess[0] = x+
              uguess[k] = U[k+1] (k < N-1), uguess[N-1] = U[N-1]
              pdata[X0] = x+
+A vehicle whose tick did not end with status 0 (QP failure, non-finite residual) keeps its
+PREVIOUS plan: in steps 2 and 3 its (X, U) are the tick's input guess instead of the failed
+iterate, so the plan it already had is carried on one more stage; ``failed`` holds the mask of
+such vehicles after ``advance`` and ``reset`` restarts chosen vehicles from the straight-line
+guess of core_solver.py:477-499 at their current state.
 The goal, bounds and corridor stay as packed.  PyTorch is used for device
 memory and for the elementwise shift / plant step only; the solve is the HIP
 library's.  There is no CPU fallback.
@@ -54,13 +59,15 @@ class RtiServer:
         self.dev = torch.device("cuda", device)
         self.B, self.N = packed.B, packed.N
         B, N = self.B, self.N
-        self.opts = opts or _lib.default_opts(self.lib)
+        # a copy: the caller's options object is not switched to real-time iteration behind its back
+        self.opts = _lib.MpcxOpts.from_buffer_copy(opts) if opts is not None else _lib.default_opts(self.lib)
         self.opts.rti = 1
         self.opts.max_obs = int(packed.n_obs.max()) if B else 0
+        self.failed = torch.zeros(B, dtype=torch.bool, device=self.dev)
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
         self.pdata = to(packed.pdata)
         self.n_obs = to(packed.n_obs)
-        self.xguess = to(packed.xguess if X is None else np.transpose(X, (1, 2, 0)))
+        self.xguess = to(packed.guess() if X is None else np.transpose(X, (1, 2, 0)))
         self.uguess = to(np.zeros((N, 2, B)) if U is None else np.transpose(U, (1, 2, 0)))
         f64 = dict(dtype=torch.float64, device=self.dev)
         i32 = dict(dtype=torch.int32, device=self.dev)
@@ -97,18 +104,46 @@ class RtiServer:
     def advance(self):
         """Steps 2 and 3 of a tick on the device; returns the applied inputs [B,2]."""
         t = self.torch
-        u0 = self.U[:, 0, :].clone()
+        ok = (self.status == 0)[:, None, None]
+        self.failed = ~ok[:, 0, 0]
+        # failed vehicles carry their previous plan (this tick's input guess) on
+        X = t.where(ok, self.X, self.xguess.permute(2, 0, 1))
+        U = t.where(ok, self.U, self.uguess.permute(2, 0, 1))
+        u0 = U[:, 0, :].clone()
         x0 = self.pdata[F_X0:F_X0 + 5].t()
         xn = plant_step(t, x0, u0, self.pdata[F_H], self.pdata[F_L])
-        self.xguess[:-1] = self.X[:, 1:, :].permute(1, 2, 0)
-        self.xguess[-1] = self.X[:, -1, :].t()
+        self.xguess[:-1] = X[:, 1:, :].permute(1, 2, 0)
+        self.xguess[-1] = X[:, -1, :].t()
         self.xguess[0] = xn.t()
         if self.N > 1:
-            self.uguess[:-1] = self.U[:, 1:, :].permute(1, 2, 0)
-        self.uguess[-1] = self.U[:, -1, :].t()
+            self.uguess[:-1] = U[:, 1:, :].permute(1, 2, 0)
+        self.uguess[-1] = U[:, -1, :].t()
         self.pdata[F_X0:F_X0 + 5] = xn.t()
         self.ticks += 1
         return u0
+
+    def reset(self, vehicles=None):
+        """Restart vehicles (index tensor / array, default: the failed ones) from the straight-line
+        guess at their current state and zero inputs.  Obstacle-free fleets only: the guess is the
+        library's device routine (the obstacle branch of the reference's guess runs on the host)."""
+        t = self.torch
+        if vehicles is None:
+            vehicles = t.nonzero(self.failed)[:, 0]
+        vehicles = t.as_tensor(vehicles, device=self.dev, dtype=t.long)
+        if vehicles.numel() == 0:
+            return 0
+        if int(self.n_obs.max()) > 0:
+            raise _lib.MpcxError("reset needs an obstacle-free fleet")
+        fresh = t.empty_like(self.xguess)
+        stream = t.cuda.current_stream()
+        rc = self.lib.mpcx_initial_guess_device(self.pdata.data_ptr(), None, self.B, self.N, fresh.data_ptr(),
+                                                stream.cuda_stream)
+        if rc != 0:
+            raise _lib.MpcxError(self.lib.mpcx_last_error().decode())
+        self.xguess[:, :, vehicles] = fresh[:, :, vehicles]
+        self.uguess[:, :, vehicles] = 0.0
+        self.failed[vehicles] = False
+        return int(vehicles.numel())
 
     def tick(self):
         self.solve()

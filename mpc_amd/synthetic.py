@@ -48,11 +48,60 @@ def random_start_goal(B, seed=SEED, with_obstacle=False):
     return start, goal, obstacle
 
 
-def synthetic_batch(B, seed=SEED, duration=5.0, dt=0.1, obstacle=False):
+def synthetic_batch(B, seed=SEED, duration=5.0, dt=0.1, obstacle=False, device_guess=False):
     """PackedBatch of B random problems (N = int(duration/dt)), without obstacles
-    or with one obstacle each."""
+    or with one obstacle each.  device_guess: leave the guess of the obstacle-free batch to the
+    library (xguess None)."""
     if obstacle:
         start, goal, obs = random_start_goal(B, seed, with_obstacle=True)
         return pack_arrays(start, goal, duration, dt, obstacle=obs)
     start, goal = random_start_goal(B, seed)
-    return pack_arrays(start, goal, duration, dt)
+    return pack_arrays(start, goal, duration, dt, device_guess=device_guess)
+
+
+def reachable_start_goal(B, seed=SEED, duration=5.0, dt=0.1, L=2.7):
+    """start, goal [B, 5] where every goal IS reachable: the start is drawn as in
+    ``random_start_goal``; the goal is the state a random admissible input sequence leads to in
+    ``duration`` seconds (five one-second pieces of constant acceleration in [-0.6, 0.6] m/s^2 and
+    steering rate in [-0.15, 0.15] rad/s, cut back where speed would leave [0, 1.8] m/s or
+    steering [-0.45, 0.45] rad; gentle enough that about 95 % of the problems also converge from
+    the reference's straight-line guess -- a feasible problem whose first linearised QP is
+    infeasible still fails, the solver takes full steps), integrated with one RK4 step of the model per interval
+    (reference core_solver.py:148-155) -- the discretisation the solver itself uses, so the
+    sequence is a feasible point of the problem up to the terminal box."""
+    rng = np.random.default_rng(seed)
+    N = int(duration / dt)
+    h = duration / N
+    start = np.zeros((B, 5))
+    start[:, 0] = rng.uniform(-20.0, 20.0, B)
+    start[:, 1] = rng.uniform(-20.0, 20.0, B)
+    start[:, 2] = rng.uniform(-np.pi / 2, np.pi / 2, B)
+    start[:, 3] = rng.uniform(0.0, 1.0, B)
+    pieces = 5
+    acc = rng.uniform(-0.6, 0.6, (pieces, B))
+    rate = rng.uniform(-0.15, 0.15, (pieces, B))
+
+    def f(s, u):
+        return np.stack([s[:, 3] * np.cos(s[:, 2]), s[:, 3] * np.sin(s[:, 2]),
+                         s[:, 3] * np.tan(s[:, 4]) / L, u[:, 0], u[:, 1]], 1)
+    x = start.copy()
+    for k in range(N):
+        j = min(pieces - 1, (k * pieces) // N)
+        a = np.clip(acc[j], (0.0 - x[:, 3]) / h, (1.8 - x[:, 3]) / h)
+        r = np.clip(rate[j], (-0.45 - x[:, 4]) / h, (0.45 - x[:, 4]) / h)
+        u = np.stack([a, r], 1)
+        k1 = f(x, u)
+        k2 = f(x + 0.5 * h * k1, u)
+        k3 = f(x + 0.5 * h * k2, u)
+        k4 = f(x + h * k3, u)
+        x = x + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+    goal = x
+    goal[:, 2] = np.clip(goal[:, 2], -np.pi + 0.05, np.pi - 0.05)
+    return start, goal
+
+
+def reachable_batch(B, seed=SEED, duration=5.0, dt=0.1, device_guess=False):
+    """PackedBatch of B problems whose goals are reachable by construction (see
+    ``reachable_start_goal``); every other field as in ``synthetic_batch``."""
+    start, goal = reachable_start_goal(B, seed, duration, dt)
+    return pack_arrays(start, goal, duration, dt, device_guess=device_guess)

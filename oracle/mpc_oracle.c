@@ -171,7 +171,8 @@ typedef struct {
     real A[NX][NX], B[NX][NU], b[NX];  /* interval k -> k+1 */
     real g[NZ], Hd[NZ];
     real c[MAXR], jx[MAXR], jy[MAXR];
-    int r0, r1;                         /* rows present: r0 <= r < r1 */
+    int r0, r1;                         /* rows present: r0 <= r < r1 and bit r of rmask set */
+    unsigned rmask;
     /* QP iterate */
     real v[NZ], qpi[NX];
     real lam_l[MAXR], lam_u[MAXR], t_l[MAXR], t_u[MAXR];
@@ -283,6 +284,8 @@ static void rk4_sens(const problem *pb, const real *x, const real *u,
     }
 }
 
+static int g_stage0_rows = 0;      /* MPCX_ORACLE_STAGE0_ROWS, see linearize() */
+
 /* ------------------------------------------------------------------ */
 /* linearisation of one SQP iteration                                   */
 /* ------------------------------------------------------------------ */
@@ -295,6 +298,15 @@ static void linearize(const problem *pb, const mpcx_opts *o, stage *st)
         if (k == 0) { s->r0 = 0; s->r1 = NU; }
         else if (k < N) { s->r0 = 0; s->r1 = 9 + pb->nobs; }
         else { s->r0 = NU; s->r1 = 9; }
+        s->rmask = ~0u;
+        /* study switch (never set by the product or the parity tests): also impose, at stage 0,
+         * the corridor rows (1) or the corridor and obstacle rows (2).  With x0 fixed they are
+         * constant rows: they enter the complementarity average, the step length and the
+         * residual norms only.  The state box stays off stage 0 (x0 is an equality there). */
+        if (k == 0 && g_stage0_rows > 0) {
+            s->r1 = (g_stage0_rows >= 2) ? 9 + pb->nobs : 9;
+            s->rmask = ~0u & ~(((1u << NX) - 1u) << NU);
+        }
         /* dynamics */
         if (k < N) {
             real xn[NX];
@@ -320,6 +332,7 @@ static void linearize(const problem *pb, const mpcx_opts *o, stage *st)
         }
         /* constraint rows: value and Jacobian */
         for (int r = s->r0; r < s->r1; ++r) {
+            if (!((s->rmask >> r) & 1u)) continue;
             if (r < NU) s->c[r] = s->u[r];
             else if (r < ROW_G0) s->c[r] = s->x[r - NU];
             else if (r < 9) {
@@ -362,6 +375,7 @@ static void nlp_residuals(const problem *pb, const stage *st, real res[4])
         if (k > 0)
             for (int i = 0; i < NX; ++i) gl[NU + i] = gl[NU + i] - s->pi[i];
         for (int r = s->r0; r < s->r1; ++r) {
+            if (!((s->rmask >> r) & 1u)) continue;
             real dl = s->nl_u[r] - s->nl_l[r];
             if (r < ROW_G0) gl[r] = gl[r] + dl;
             else {
@@ -412,6 +426,7 @@ static void qp_residuals(const problem *pb, stage *st, int m_total, qp_res *R)
             for (int i = 0; i < NX; ++i) s->rg[NU + i] = s->rg[NU + i] - s->qpi[i];
         real ssum = 0.0;     /* complementarity products of this stage, then added to the total */
         for (int r = s->r0; r < s->r1; ++r) {
+            if (!((s->rmask >> r) & 1u)) continue;
             real jv = row_dot(s, r, s->v);
             real dl = s->lam_u[r] - s->lam_l[r];
             if (r < ROW_G0) s->rg[r] = s->rg[r] + dl;
@@ -460,6 +475,7 @@ static void qp_init(const problem *pb, const mpcx_opts *o, stage *st)
         if (k == 0)
             for (int i = 0; i < NX; ++i) s->v[NU + i] = pb->x0[i] - s->x[i];
         for (int r = s->r0; r < s->r1; ++r) {
+            if (!((s->rmask >> r) & 1u)) continue;
             real dl = lo[r] - s->c[r], du = up[r] - s->c[r];
             real tl, tu;
             if (r < ROW_G0) {
@@ -508,6 +524,7 @@ static void qp_build_rhs(const problem *pb, stage *st, int mode, real sigma_mu)
         }
         for (int j = 0; j < NZ; ++j) s->gt[j] = s->rg[j];
         for (int r = s->r0; r < s->r1; ++r) {
+            if (!((s->rmask >> r) & 1u)) continue;
             real til = (real)1.0 / s->t_l[r], tiu = (real)1.0 / s->t_u[r];
             real rml = s->lam_l[r] * s->t_l[r], rmu = s->lam_u[r] * s->t_u[r];
             if (mode == 1) {
@@ -680,6 +697,7 @@ static real qp_step_length(const problem *pb, stage *st, int mode, real sigma_mu
         real num = 1.0, den = 1.0;    /* smallest ratio of this stage; the step is the min over stages */
         real s1k = 0.0, s2k = 0.0;    /* sums of this stage, then added to the totals */
         for (int r = s->r0; r < s->r1; ++r) {
+            if (!((s->rmask >> r) & 1u)) continue;
             real til = (real)1.0 / s->t_l[r], tiu = (real)1.0 / s->t_u[r];
             real rml = s->lam_l[r] * s->t_l[r], rmu = s->lam_u[r] * s->t_u[r];
             if (mode == 1) {
@@ -728,6 +746,7 @@ static void qp_update(const problem *pb, const mpcx_opts *o, stage *st, int mode
     for (int k = 0; k <= N; ++k) {
         stage *s = &st[k];
         for (int r = s->r0; r < s->r1; ++r) {
+            if (!((s->rmask >> r) & 1u)) continue;
             real til = (real)1.0 / s->t_l[r], tiu = (real)1.0 / s->t_u[r];
             real rml = s->lam_l[r] * s->t_l[r], rmu = s->lam_u[r] * s->t_u[r];
             if (mode == 1) {
@@ -765,7 +784,8 @@ static int qp_solve(const problem *pb, const mpcx_opts *o, stage *st, int *iters
 {
     const int N = pb->N;
     int m_total = 0;
-    for (int k = 0; k <= N; ++k) m_total += 2 * (st[k].r1 - st[k].r0);
+    for (int k = 0; k <= N; ++k)
+        for (int r = st[k].r0; r < st[k].r1; ++r) m_total += 2 * (int)((st[k].rmask >> r) & 1u);
     qp_res R;
     qp_init(pb, o, st);
     qp_residuals(pb, st, m_total, &R);
@@ -878,7 +898,8 @@ static void sqp_solve(const problem *pb, const mpcx_opts *o, stage *st, outcome 
             for (int i = 0; i < NX; ++i) s->x[i] = s->x[i] + s->v[NU + i];
             if (k < N) for (int c = 0; c < NU; ++c) s->u[c] = s->u[c] + s->v[c];
             if (k > 0) for (int i = 0; i < NX; ++i) s->pi[i] = s->qpi[i];
-            for (int r = s->r0; r < s->r1; ++r) { s->nl_l[r] = s->lam_l[r]; s->nl_u[r] = s->lam_u[r]; }
+            for (int r = s->r0; r < s->r1; ++r)
+                if ((s->rmask >> r) & 1u) { s->nl_l[r] = s->lam_l[r]; s->nl_u[r] = s->lam_u[r]; }
         }
         if (o->rti) { status = MPCX_SUCCESS; break; }
     }
@@ -951,6 +972,7 @@ int mpcx_oracle_solve_batch(const mpcx_batch *in, const mpcx_opts *o, mpcx_resul
 {
     if (!in || !o || !out || in->N < 1 || b0 < 0 || b1 > in->B) return MPCX_E_BADARG;
     g_debug = getenv("MPCX_ORACLE_DEBUG") ? atoi(getenv("MPCX_ORACLE_DEBUG")) : 0;
+    g_stage0_rows = getenv("MPCX_ORACLE_STAGE0_ROWS") ? atoi(getenv("MPCX_ORACLE_STAGE0_ROWS")) : 0;
     const int N = in->N, B = in->B;
     int fail = 0;
 #ifdef _OPENMP

@@ -12,6 +12,7 @@ from mpc_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "libmpc_oracle.so")
 ORACLE_COUNT_SO = os.path.join(ROOT, "oracle", "libmpc_oracle_count.so")
+ORACLE_FAST_SO = os.path.join(ROOT, "oracle", "libmpc_oracle_fast.so")      # -O3 build: the timed CPU baseline
 
 _cache = {}
 
@@ -48,6 +49,9 @@ def solve_packed(packed, opts=None, device=0, nthreads=None, lib=None):
     out = _lib.alloc_result(packed.B, packed.N)
     if packed.B == 0:
         return out
+    if packed.xguess is None:      # the oracle has no guess of its own: the host loop's (reference :477-499)
+        import dataclasses
+        packed = dataclasses.replace(packed, xguess=packed.guess())
     b = _lib.batch_struct(packed)
     r = _lib.result_struct(out)
     if nthreads is None:

@@ -23,10 +23,11 @@ def test_exports_match_header():
     names = declared_functions()
     assert {"mpcx_version", "mpcx_last_error", "mpcx_opts_default", "mpcx_device_count",
             "mpcx_solve_batch", "mpcx_workspace_bytes", "mpcx_solve_batch_device",
-            "mpcx_probe_sincos"} <= set(names)
+            "mpcx_probe_sincos", "mpcx_ctx_create", "mpcx_ctx_solve", "mpcx_ctx_destroy",
+            "mpcx_max_horizon"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mpcx.h but not exported"
-    assert lib.mpcx_version() == 103
+    assert lib.mpcx_version() == 104
 
 
 def test_struct_layout_and_defaults():
@@ -56,6 +57,25 @@ def test_bad_arguments_and_no_device():
     assert lib.mpcx_solve_batch(C.byref(b), C.byref(o), C.byref(r), 0) == -1
     o.max_obs = -1
     assert lib.mpcx_workspace_bytes(0, 50) == 0 and lib.mpcx_workspace_bytes(64, 50) > 0
+    # horizons whose wavefront workspace would pass the 4 GiB that 32-bit offsets reach are refused
+    nmax = lib.mpcx_max_horizon()
+    assert 30_000 < nmax < 60_000
+    b.N = nmax + 1
+    assert lib.mpcx_solve_batch(C.byref(b), C.byref(o), C.byref(r), 0) == -1
+    assert b"too large" in lib.mpcx_last_error()
+    b.N = p.N
+    # a batch with obstacles and no guess is refused by the host entry point (the guess of
+    # core_solver.py:360-473 is the caller's)
+    if lib.mpcx_device_count() > 0:
+        b.xguess = None
+        no = np.ones(p.B, dtype=np.int32)
+        b.n_obs = no.ctypes.data
+        assert lib.mpcx_solve_batch(C.byref(b), C.byref(o), C.byref(r), 0) == -1
+        assert b"xguess is NULL" in lib.mpcx_last_error()
+        b = _lib.batch_struct(p)
+    h = C.c_void_p()
+    assert lib.mpcx_ctx_create(None, 0) == -1
+    lib.mpcx_ctx_destroy(None)
     if lib.mpcx_device_count() == 0:
         assert lib.mpcx_solve_batch(C.byref(b), C.byref(o), C.byref(r), 0) == -2      # MPCX_E_NODEVICE
         x = np.zeros(4)

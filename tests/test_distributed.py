@@ -33,9 +33,13 @@ WORKER = textwrap.dedent("""
     from mpc_amd.synthetic import synthetic_batch
     dist.init_process_group("gloo")
     packed = synthetic_batch(101)
-    full = solve_sharded(packed, lambda sub: oracle_lib.solve_packed(sub, nthreads=2))
+    solve = lambda sub: oracle_lib.solve_packed(sub, nthreads=2)
+    full = solve_sharded(packed, solve, everyone=False)            # gather to rank 0
+    assert (full is None) == (dist.get_rank() != 0)
     if dist.get_rank() == 0:
         np.savez({out!r}, **full)
+    everywhere = solve_sharded(packed, solve, everyone=True)       # all-gather
+    np.savez({out!r} + f".rank{{dist.get_rank()}}.npz", **everywhere)
     dist.destroy_process_group()
 """)
 
@@ -54,6 +58,24 @@ def test_two_rank_gloo_matches_single_process(tmp_path, oracle):
     from mpc_amd.synthetic import synthetic_batch
     ref = oracle.solve_packed(synthetic_batch(101))
     got = np.load(out)
-    for k in ref:
-        assert got[k].shape == ref[k].shape, k
-        assert np.array_equal(got[k], ref[k], equal_nan=True), k
+    for path in (out, out + ".rank0.npz", out + ".rank1.npz"):
+        got = np.load(path)
+        for k in ref:
+            assert got[k].shape == ref[k].shape, (path, k)
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (path, k)
+
+
+def test_bench_refuses_to_report_more_gpus_than_it_has():
+    """`bench.py --gpus N` without a launcher starts N ranks itself; with fewer devices visible it
+    fails loudly instead of printing a line (here: as many GPUs as this host has, plus two)."""
+    import torch
+    n = torch.cuda.device_count() + 2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
+                        "--batch", "64"], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr and r.stdout.strip() == ""
+    # under a launcher whose world size disagrees with --gpus it is an error too
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and r.stdout.strip() == ""

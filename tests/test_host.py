@@ -181,6 +181,59 @@ def test_failure_contract(oracle, capsys):
     assert find_paths([e2], s, solver=oracle.solve_packed) == [None]
 
 
+def test_find_paths_isolates_bad_problems(oracle, capsys):
+    """One problem that cannot be set up fails alone (reference: one find_path call per problem,
+    core_solver.py:540-562; the grid loop keeps going, grid_path_plan.py:78-89)."""
+    good, s = cases.make_scenario("line")
+    same = EgoConfig()                       # start == goal: corridor_cal raises
+    same.state_start = [1, 1, 0, 0, 0]
+    same.state_final = [1, 1, 0, 0, 0]
+    many = EgoConfig()                       # more obstacles than a problem can carry
+    many.state_start = list(good.state_start)
+    many.state_final = list(good.state_final)
+    many.obstacles = [[5.0, 9.0, 0.5, 0.1]] * 5
+    short = EgoConfig()                      # a state of the wrong length smuggled past the setter
+    short._state_start = [0, 0, 0]
+    for e in (same, many, short):
+        e.verbose = False
+    res = find_paths([good, same, good, many, short, good], s, solver=oracle.solve_packed)
+    assert [r is not None for r in res] == [True, False, True, False, False, True]
+    alone = find_path(good, s, solver=oracle.solve_packed)
+    for i in (0, 2, 5):
+        assert np.array_equal(res[i]["x"], alone["x"]) and np.array_equal(res[i]["u"], alone["u"])
+    # per-problem horizons: a bad SimConfig fails its own problem only
+    bad_sim = SimConfig()
+    bad_sim.dt = 0.0
+    res = find_paths([good, good], [s, bad_sim], solver=oracle.solve_packed)
+    assert res[0] is not None and res[1] is None
+    # verbose problems report their own error
+    same.verbose = True
+    capsys.readouterr()
+    find_paths([same], s, solver=oracle.solve_packed)
+    assert "Points A and B cannot be the same" in capsys.readouterr().out
+    # generate_controls_batch without an error dict still raises, like one reference call would
+    from mpc_amd.core_solver import generate_controls_batch
+    with pytest.raises(ValueError):
+        generate_controls_batch([good, same], s, solver=oracle.solve_packed)
+
+
+def test_guess_left_to_the_library_is_the_host_loop():
+    """A batch packed without a guess (xguess None: the library computes it on the device) yields,
+    through PackedBatch.guess(), exactly the host loop's array; with obstacles the guess is packed."""
+    start, goal = random_start_goal(100, seed=3)
+    a = bt.pack_arrays(start, goal, 5.0)
+    b = bt.pack_arrays(start, goal, 5.0, device_guess=True)
+    assert b.xguess is None and np.array_equal(a.pdata, b.pdata) and np.array_equal(b.guess(), a.xguess)
+    assert np.array_equal(a.pdata[bt.F_CW], np.full(100, 15.0))
+    assert b.slice(10, 20).xguess is None and b.slice(10, 20).B == 10
+    ego, sim = cases.make_scenario("path_finder")
+    p = bt.pack_problems([ego], sim, device_guess=True)
+    assert p.xguess is not None and p.pdata[bt.F_CW, 0] == 10.0
+    ego, sim = cases.make_scenario("line")
+    p = bt.pack_problems([ego], sim, device_guess=True)
+    assert p.xguess is None and np.array_equal(p.guess()[:, :, 0], bt.initial_guess(ego, p.N))
+
+
 def test_no_silent_cpu_fallback():
     """Without a HIP device the product path must raise, not compute."""
     from mpc_amd import _lib
