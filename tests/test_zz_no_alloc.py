@@ -1,0 +1,70 @@
+"""GPU: the entry point that allocates nothing (mpcx_solve_batch_static, workspace = the device
+array built into the library) against mpcx_solve_batch_device with a caller workspace, through
+the C ABI: bit-identical outputs on two calls in a row, the second with a smaller input, and a
+clear refusal of a horizon the built-in scratch cannot hold."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from mpc_amd import _lib
+from mpc_amd.batch import pack_problems
+from mpc_amd.synthetic import synthetic_batch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("X", "U", "status", "sqp_iter", "qp_iter", "cost", "res")
+
+
+def _device_solve(lib, packed, static):
+    dev = torch.device("cuda", 0)
+    B, N = packed.B, packed.N
+    d_pd = torch.from_numpy(packed.pdata).to(dev)
+    d_no = torch.from_numpy(packed.n_obs).to(dev)
+    d_xg = torch.from_numpy(packed.guess()).to(dev)
+    f64, i32 = dict(dtype=torch.float64, device=dev), dict(dtype=torch.int32, device=dev)
+    out = {"X": torch.full((B, N + 1, 5), np.nan, **f64), "U": torch.full((B, N, 2), np.nan, **f64),
+           "status": torch.full((B,), -1, **i32), "sqp_iter": torch.full((B,), -1, **i32),
+           "qp_iter": torch.full((B,), -1, **i32), "cost": torch.full((B,), np.nan, **f64),
+           "res": torch.full((4, B), np.nan, **f64)}
+    bs = _lib.MpcxBatch(B, N, d_pd.data_ptr(), d_no.data_ptr(), d_xg.data_ptr(), None)
+    rs = _lib.MpcxResult(*(out[k].data_ptr() for k in KEYS))
+    o = _lib.default_opts(lib)
+    stream = torch.cuda.current_stream().cuda_stream
+    if static:
+        before = torch.cuda.memory_allocated()
+        rc = lib.mpcx_solve_batch_static(C.byref(bs), C.byref(o), C.byref(rs), stream)
+        assert torch.cuda.memory_allocated() == before
+    else:
+        ws_bytes = lib.mpcx_workspace_bytes(B, N)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = lib.mpcx_solve_batch_device(C.byref(bs), C.byref(o), C.byref(rs), ws.data_ptr(), ws_bytes, stream)
+    assert rc == 0, lib.mpcx_last_error()
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def test_static_scratch_entry_point_matches_device_entry_point():
+    lib = _lib.load_library()
+    first = synthetic_batch(3000)                                     # more problems than the scratch holds at once
+    second = pack_problems(*cases.obstacle_problems(40, 13.0))       # smaller, another horizon, obstacle rows
+    for packed in (first, second):
+        want = _device_solve(lib, packed, static=False)
+        got = _device_solve(lib, packed, static=True)
+        cases.assert_same_solution(got, want, f"static scratch, B={packed.B} N={packed.N}")
+        assert (got["status"] >= 0).all() and (want["status"] == 0).any()
+    # a horizon whose single-wavefront workspace exceeds the built-in scratch is refused, nothing is launched
+    big = synthetic_batch(2, duration=80.0)
+    assert big.N == 800
+    dev = torch.device("cuda", 0)
+    d_pd = torch.from_numpy(big.pdata).to(dev)
+    d_no = torch.from_numpy(big.n_obs).to(dev)
+    dummy = torch.zeros(16, dtype=torch.float64, device=dev)
+    bs = _lib.MpcxBatch(big.B, big.N, d_pd.data_ptr(), d_no.data_ptr(), None, None)
+    rs = _lib.MpcxResult(*([dummy.data_ptr()] * 7))
+    o = _lib.default_opts(lib)
+    assert lib.mpcx_solve_batch_static(C.byref(bs), C.byref(o), C.byref(rs), None) == -1
+    assert b"built-in scratch" in lib.mpcx_last_error()
