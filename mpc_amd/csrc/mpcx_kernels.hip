@@ -862,7 +862,7 @@ DEV double psym(const double *P, int i, int j) { return (i >= j) ? P[tri(i, j)] 
 
 // what the row part of a B0 stage hands to the Riccati part (and, for vx / qpi, to stage k-1)
 struct B0Out {
-    double gt[NZ], Ht[NZ], hxx, hxy, hyy, rb[NX];
+    double gt[NZ], rg[NZ], Ht[NZ], hxx, hxy, hyy, rb[NX];
     AB ab;
     double vx[NX], qpi[NX];
     double ng, nb, nd, nm, ssum;
@@ -877,16 +877,15 @@ struct B0In {
     double bv[NX];
 };
 
-// first half: all loads of the stage, then the pending step on v and on the dynamics multiplier
+// first half: all loads of the stage (dpi: step of the dynamics multiplier, used by the apply part only)
 template <int NH, int KIND>
-DEV void stage_B0_head(const Lane &L, int k, const Step &sp, B0In<NH> &in, const KR &kr = KR{false, false})
+DEV void stage_B0_load(const Lane &L, int k, const Step &sp, B0In<NH> &in, double *dpi, const KR &kr = KR{false, false})
 {
     typedef Map<NH> M;
     // ---- loads ----
     const int sol = (sp.mode == 2) ? M::SOL2 : 0;      // which of the two stored solutions is the step
-    double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&vo)[NZ] = in.vo, (&dv)[NZ] = in.dv,
+    double (&x)[NX] = in.x, (&u)[NU] = in.u, (&vo)[NZ] = in.vo, (&dv)[NZ] = in.dv,
            (&dva)[NZ] = in.dva, (&qpi)[NX] = in.qpi;
-    double dpi[NX];
     double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
            (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
     load_xu<NH, KIND>(L, k, kr, x, u);
@@ -925,13 +924,21 @@ DEV void stage_B0_head(const Lane &L, int k, const Step &sp, B0In<NH> &in, const
         for (int i = 0; i < NX; ++i) bv[i] = ldw<KIND>(L, k, M::BV + i);
     }
     __builtin_amdgcn_sched_barrier(0);     // every load of the stage is in flight before the first use
-    // ---- pending step on the primal and the dynamics multiplier ----
+}
+
+// the pending step on the primal and the dynamics multiplier.  ST = false: nothing is stored, the
+// caller keeps the stage in registers (in.v, in.qpi are the updated values either way)
+template <int NH, int KIND, bool ST = true>
+DEV void stage_B0_apply(const Lane &L, int k, const Step &sp, B0In<NH> &in, const double *dpi, const KR &kr = KR{false, false})
+{
+    typedef Map<NH> M;
+    double (&v)[NZ] = in.v, (&vo)[NZ] = in.vo, (&dv)[NZ] = in.dv, (&qpi)[NX] = in.qpi;
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
         v[j] = vo[j];
         if (var_present<KIND>(j)) {
             v[j] = (sp.have && var_on<KIND>(kr, j)) ? fma(sp.alpha, dv[j], vo[j]) : vo[j];
-            stw<KIND>(L, k, M::V + j, v[j]);
+            if (ST) stw<KIND>(L, k, M::V + j, v[j]);
         }
     }
     if (KIND != FIRST) {
@@ -939,14 +946,22 @@ DEV void stage_B0_head(const Lane &L, int k, const Step &sp, B0In<NH> &in, const
         for (int i = 0; i < NX; ++i) {
             qpi[i] = sp.have ? fma(sp.alpha, dpi[i], qpi[i]) : qpi[i];
             qpi[i] = is_first<KIND>(kr) ? 0.0 : qpi[i];
-            stw<KIND>(L, k, M::QPI + i, qpi[i]);
+            if (ST) stw<KIND>(L, k, M::QPI + i, qpi[i]);
         }
     }
 }
 
+template <int NH, int KIND>
+DEV void stage_B0_head(const Lane &L, int k, const Step &sp, B0In<NH> &in, const KR &kr = KR{false, false})
+{
+    double dpi[NX];
+    stage_B0_load<NH, KIND>(L, k, sp, in, dpi, kr);
+    stage_B0_apply<NH, KIND>(L, k, sp, in, dpi, kr);
+}
+
 // second half: rows, residuals, barrier Hessian, affine right-hand side.  vxn / qpin: updated
 // x-part of v and dynamics multiplier of stage k+1.
-template <int NH, int KIND>
+template <int NH, int KIND, bool ST = true>
 DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, const Step &sp, B0In<NH> &in,
                        const double *vxn, const double *qpin, B0Out &out, const KR &kr = KR{false, false})
 {
@@ -1006,10 +1021,13 @@ DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
             t = fma(sp.alpha, dlu, l_u); t = (t < o.lam_min) ? o.lam_min : t; l_u = sp.have ? t : l_u;
             t = fma(sp.alpha, dtl, t_l); t = (t < o.t_min) ? o.t_min : t; t_l = sp.have ? t : t_l;
             t = fma(sp.alpha, dtu, t_u); t = (t < o.t_min) ? o.t_min : t; t_u = sp.have ? t : t_u;
-            stw<KIND>(L, k, M::LAML + r, l_l);
-            stw<KIND>(L, k, M::LAMU + r, l_u);
-            stw<KIND>(L, k, M::TL + r, t_l);
-            stw<KIND>(L, k, M::TU + r, t_u);
+            if (ST) {
+                stw<KIND>(L, k, M::LAML + r, l_l);
+                stw<KIND>(L, k, M::LAMU + r, l_u);
+                stw<KIND>(L, k, M::TL + r, t_l);
+                stw<KIND>(L, k, M::TU + r, t_u);
+            }
+            ll[r] = l_l; lu[r] = l_u; tl[r] = t_l; tu[r] = t_u;      // (in.* hold the updated values on return)
         }
         double jv = jdot(r, jx, jy, v);
         double dlm = l_u - l_l;
@@ -1051,7 +1069,8 @@ DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
     double gt[NZ];
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
-        stw<KIND>(L, k, M::RG + j, rg[j]);
+        if (ST) stw<KIND>(L, k, M::RG + j, rg[j]);
+        out.rg[j] = rg[j];
         if (var_present<KIND>(j)) out.ng = var_on<KIND>(kr, j) ? dmax(out.ng, dabs(rg[j])) : out.ng;
         gt[j] = rg[j];
     }
@@ -1077,7 +1096,7 @@ DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
     #pragma unroll
         for (int i = 0; i < NX; ++i) {
             out.rb[i] = out.rb[i] - vxn[i];
-            stw<KIND>(L, k, M::RB + i, out.rb[i]);
+            if (ST) stw<KIND>(L, k, M::RB + i, out.rb[i]);
             out.nb = is_last<KIND>(kr) ? out.nb : dmax(out.nb, dabs(out.rb[i]));
         }
     }
@@ -1268,15 +1287,23 @@ struct BsOut {
     AB ab;
 };
 
-// Bs, row part of stage k: the two right-hand sides, and the stored factors of the stage
+// what the row part of Bs reads of a stage besides the factors that go straight into BsOut
+template <int NH>
+struct BsIn {
+    double x[NX], u[NU], v[NZ], dva[NZ];
+    double ll[Map<NH>::R], lu[Map<NH>::R], tl[Map<NH>::R], tu[Map<NH>::R], til_[Map<NH>::R], tiu_[Map<NH>::R];
+};
+
+// Bs, loads of stage k: the iterate and the affine step (in), the stationarity residual (out.gt1)
+// and the stored factors of the stage (out)
 template <int NH, int KIND>
-DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu, BsOut &out,
-                       const KR &kr = KR{false, false})
+DEV void stage_Bs_load(const Lane &L, int k, BsIn<NH> &in, BsOut &out, const KR &kr = KR{false, false})
 {
     typedef Map<NH> M;
-    double x[NX], u[NU], v[NZ], dva[NZ];
-    double *gt1 = out.gt1, *gt2 = out.gt2;
-    double ll[M::R], lu[M::R], tl[M::R], tu[M::R], til_[M::R], tiu_[M::R];
+    double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&dva)[NZ] = in.dva;
+    double *gt1 = out.gt1;
+    double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
+           (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
     load_xu<NH, KIND>(L, k, kr, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
@@ -1314,6 +1341,18 @@ DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
         out.d1 = ldw<KIND>(L, k, M::LDL + 2);
     }
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// Bs, row part of stage k: the two right-hand sides; out.gt1 holds the stationarity residual on entry
+template <int NH, int KIND>
+DEV void stage_Bs_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, double sigma_mu, const BsIn<NH> &in,
+                          BsOut &out, const KR &kr = KR{false, false})
+{
+    typedef Map<NH> M;
+    const double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&dva)[NZ] = in.dva;
+    double *gt1 = out.gt1, *gt2 = out.gt2;
+    const double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
+                 (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
 #pragma unroll
     for (int j = 0; j < NZ; ++j) gt2[j] = gt1[j];
 #pragma unroll
@@ -1346,6 +1385,15 @@ DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
             gt2[3] = pr ? fma(jy, q2, gt2[3]) : gt2[3];
         }
     }
+}
+
+template <int NH, int KIND>
+DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu, BsOut &out,
+                       const KR &kr = KR{false, false})
+{
+    BsIn<NH> in;
+    stage_Bs_load<NH, KIND>(L, k, in, out, kr);
+    stage_Bs_compute<NH, KIND>(L, o, pc, sigma_mu, in, out, kr);
 }
 
 // Bs, recursion part of a stage: pn1 / pn2 hold p(k+1) of the two systems on entry, p(k) on
@@ -1516,9 +1564,12 @@ DEV void stage_F_load(const Lane &L, int k, FIn<NH, NS> &in, const KR &kr = KR{f
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NH, int KIND, int NS>
+// ST = false: nothing is stored; the steps of the stage come back in dvo[q][0..6] and (NS = 2) the
+// steps of the dynamics multiplier in dpo[q][0..4]
+template <int NH, int KIND, int NS, bool ST = true>
 DEV void stage_F_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu,
-                         FIn<NH, NS> &in, double (*dx)[NX], FAcc &a, const KR &kr = KR{false, false})
+                         FIn<NH, NS> &in, double (*dx)[NX], FAcc &a, const KR &kr = KR{false, false},
+                         double (*dvo)[NZ] = nullptr, double (*dpo)[NX] = nullptr)
 {
     typedef Map<NH> M;
     double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&dva)[NZ] = in.dva;
@@ -1539,7 +1590,8 @@ DEV void stage_F_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, in
                 double acc = pv[q][i];
 #pragma unroll
                 for (int j = 0; j < NX; ++j) acc = fma(psym(Pk, i, j), dx[q][j], acc);
-                stw<KIND>(L, k, M::DPI + q * M::SOL2 + i, acc);
+                if (ST) stw<KIND>(L, k, M::DPI + q * M::SOL2 + i, acc);
+                else dpo[q][i] = acc;
             }
         }
         if (KIND != LAST) {
@@ -1548,7 +1600,10 @@ DEV void stage_F_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, in
             dvk[q][1] = is_last<KIND>(kr) ? 0.0 : dvk[q][1];
         }
 #pragma unroll
-        for (int j = 0; j < NZ; ++j) stw<KIND>(L, k, (NS == 1 ? M::DVA : M::DV + q * M::SOL2) + j, dvk[q][j]);
+        for (int j = 0; j < NZ; ++j) {
+            if (ST) stw<KIND>(L, k, (NS == 1 ? M::DVA : M::DV + q * M::SOL2) + j, dvk[q][j]);
+            else dvo[q][j] = dvk[q][j];
+        }
     }
     double s1k = 0.0, s2k = 0.0, knum[NS], kden[NS];
 #pragma unroll
@@ -1666,6 +1721,15 @@ __device__ unsigned long long g_stamps[2048][N_STAMP];
         st_t0 = __builtin_amdgcn_s_memtime();                                          \
     } while (0)
 // wall-clock marks (100 MHz counter): the slot keeps the time of the first call
+#define STAMP_N(slot, n)                                                               \
+    do {                                                                               \
+        unsigned long long st_t1 = __builtin_amdgcn_s_memtime();                       \
+        if (threadIdx.x == 0) {                                                        \
+            g_stamps[blockIdx.x][2 * (slot)] += st_t1 - st_t0;                         \
+            g_stamps[blockIdx.x][2 * (slot) + 1] += (n);                               \
+        }                                                                              \
+        st_t0 = __builtin_amdgcn_s_memtime();                                          \
+    } while (0)
 #define MARK(slot)                                                                     \
     do {                                                                               \
         if (g_stamps[blockIdx.x][2 * (slot)] == 0) g_stamps[blockIdx.x][2 * (slot)] = wall_clock64(); \
@@ -1685,6 +1749,7 @@ __device__ unsigned long long g_stamps[2048][N_STAMP];
 #define STAMP_DECL() ((void)0)
 #define STAMP_BEGIN() ((void)0)
 #define STAMP(slot, pred) ((void)0)
+#define STAMP_N(slot, n) ((void)0)
 #define SUB_BEGIN() ((void)0)
 #define SUB_END(slot) ((void)0)
 #endif
@@ -2067,6 +2132,299 @@ __device__ __attribute__((noinline)) double coop_F(COOP_PARAMS, const mpcx_opts 
     return alpha[0];
 }
 
+// ---------------------------------------------------------------------------
+// A BURST of interior-point iterations of one problem (N < 64), the wavefront with a lane per
+// stage and the stage RESIDENT in the lane's registers: the iterate, the linearisation, the
+// multipliers and the pending step are loaded once, every iteration of the burst hands its
+// results to the next in registers (the four sweeps of an iteration are one instruction stream
+// here, their row parts and lane pipelines the same code as in coop_B0_block / coop_F / coop_Bs),
+// and the stage goes back to the workspace once at the end.  Between the first load and the
+// last store a burst touches no memory but the problem constants in LDS.  The operations and
+// their order per problem are those of the separate sweeps.
+// Results (wave-uniform) are left in the carry words behind the sweeps' result slots.
+// ---------------------------------------------------------------------------
+// what a lane of the solve kernel is doing (see the kernel below)
+enum LaneState {
+    LS_FETCH = 0,   // needs a problem
+    LS_LIN = 1,     // needs sweep L (new SQP iteration)
+    LS_QP = 2,      // inside the interior point: one iteration per tick
+    LS_OUT = 3,     // problem ended, results not written yet
+    LS_DONE = 4     // no problems left
+};
+
+enum { BR_STATE = 0, BR_STATUS, BR_ADD_TOTAL, BR_ADD_SQP, BR_QIT, BR_HAVE, BR_MODE, BR_SIGMA_MU, BR_ALPHA, BR_DONE, BR_N };
+static_assert(BR_N <= CY_N, "burst results fit the carry words");
+static_assert(MPCX_STORE_RECIP == 0, "the resident burst recomputes the slack reciprocals");
+
+template <int NH>
+__device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opts *op, int sp_have_mode,
+                                                     double sp_sigma_mu, double sp_alpha, int m_total, int qit_max,
+                                                     ldouble *ret)
+{
+    // (two small integers per argument: the arguments then fit the registers of the calling convention)
+    const bool sp_have = ((sp_have_mode >> 8) & 1) != 0;
+    const int sp_mode = sp_have_mode & 255;
+    int qit = qit_max & 0xffff;
+    const int max_iters = qit_max >> 16;
+    typedef Map<NH> M;
+    COOP_UNPACK(NH);
+    const mpcx_opts &o = *op;
+    const int N = C.N;
+    const int j = (int)threadIdx.x;
+    const int kj = j;
+    const bool on = kj <= N;
+    const Lane S = stage_lane(C, (unsigned)kj);
+    const KR kr = {kj == 0, kj == N};
+    ldouble *carry = ret - j + 5 * 64;      // same address in every lane
+    Step sp;
+    sp.have = sp_have; sp.mode = sp_mode; sp.sigma_mu = sp_sigma_mu; sp.alpha = sp_alpha;
+    // ---- this lane's stage ----
+    B0In<NH> R = {};
+    double dpi[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dpi[i] = 0.0;
+    if (on) stage_B0_load<NH, ANY>(S, 0, sp, R, dpi, kr);
+    int n_state = LS_QP, n_status = -1, add_total = 0, add_sqp = 0, done = 0;
+    SUB_BEGIN();
+    SUB_END(27);
+    for (;;) {
+        // ================= B0: pending step, residuals, barrier Hessian, factorisation =================
+        if (on) stage_B0_apply<NH, ANY, false>(S, 0, sp, R, dpi, kr);
+        double vxn[NX], qpin[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            vxn[i] = lane_above<true>(R.v[NU + i], 0.0);
+            qpin[i] = lane_above<true>(R.qpi[i], 0.0);
+        }
+        B0Out t = {};
+        if (on) stage_B0_tail<NH, ANY, false>(S, o, pc, 0, sp, R, vxn, qpin, t, kr);
+#pragma unroll
+        for (int jj = 0; jj < NZ; ++jj) R.vo[jj] = R.v[jj];      // the iterate the next pending step starts from
+        const int kend = N;
+        const double Rg = uniform(wave_max(t.ng)), Rb = uniform(wave_max(t.nb)), Rd = uniform(wave_max(t.nd)),
+                     Rm = uniform(wave_max(t.nm));
+        double sum = 0.0;
+        for (int s = 0; s <= kend; ++s) {      // the complementarity sum: a chain from stage N down to stage 0
+            const double in = lane_above<true>(sum, 0.0);
+            sum = (j <= kend) ? in + t.ssum : in;
+        }
+        const double mu = uniform(bcast(sum, 0) / (double)m_total);
+        SUB_END(16);
+        double Po[15], po[NX];
+        RicOut ro = {};
+#pragma unroll
+        for (int i = 0; i < NX; ++i) po[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) Po[i] = 0.0;
+        // ================= end of the QP? =================
+        int qs = -1;
+        if (!(finite_d(Rg) && finite_d(Rb) && finite_d(Rd) && finite_d(Rm))) qs = 3;
+        else if (Rg < o.qp_tol_stat && Rb < o.qp_tol_eq && Rd < o.qp_tol_ineq && Rm < o.qp_tol_comp) qs = 0;
+        else if (qit >= o.max_qp_iter) qs = 1;
+        if (qs >= 0) {
+            add_total = qit;
+            add_sqp = 1;
+            if (qs == 3) { n_status = MPCX_QP_FAILURE; n_state = LS_OUT; }
+            else n_state = LS_LIN;
+            break;
+        }
+        // ================= Riccati factorisation and the affine backward substitution =================
+        if (kj == N) stage_B0_ric<LAST>(S, t, Po, po, Po, po, ro);
+        for (int s = 0; s < N; ++s) {
+            double Pi[15], pi[NX];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) Pi[i] = lane_above<true>(Po[i], 0.0);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) pi[i] = lane_above<true>(po[i], 0.0);
+            if (kj < N) stage_B0_ric<MID>(S, t, Pi, pi, Po, po, ro);
+        }
+        SUB_END(17);
+        // ================= F (affine): predictor step, its length, centring sums =================
+        double a_aff, S1, S2;
+        {
+            FIn<NH, 1> ld = {};
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { ld.x[i] = R.x[i]; ld.rb[i] = t.rb[i]; ld.kg[0][i] = ro.K[0][i]; ld.kg[1][i] = ro.K[1][i]; }
+            ld.u[0] = R.u[0]; ld.u[1] = R.u[1];
+            ld.kv[0][0] = ro.kv[0]; ld.kv[0][1] = ro.kv[1];
+#pragma unroll
+            for (int jj = 0; jj < NZ; ++jj) { ld.v[jj] = R.v[jj]; ld.dva[jj] = 0.0; }
+#pragma unroll
+            for (int r = 0; r < M::R; ++r) { ld.ll[r] = R.ll[r]; ld.lu[r] = R.lu[r]; ld.tl[r] = R.tl[r]; ld.tu[r] = R.tu[r]; }
+            ld.ab = R.ab;
+            double dxi[1][NX], dxo[1][NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { dxi[0][i] = 0.0; dxo[0][i] = 0.0; }
+            for (int s = 0; s <= kend; ++s) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) dxi[0][i] = lane_below<true>(dxo[0][i], 0.0);
+                if (kj < N) {
+                    double du[NU];
+                    F_rec(C, ld.ab, ld.kg, ld.kv[0], ld.rb, dxi[0], du, dxo[0]);
+                }
+            }
+            FAcc a = {{1.0, 1.0}, 0.0, 0.0};
+            double dvo[1][NZ];
+#pragma unroll
+            for (int jj = 0; jj < NZ; ++jj) dvo[0][jj] = 0.0;
+            if (on) stage_F_compute<NH, ANY, 1, false>(S, o, pc, 0, 0.0, ld, dxi, a, kr, dvo, nullptr);
+#pragma unroll
+            for (int jj = 0; jj < NZ; ++jj) R.dva[jj] = dvo[0][jj];
+            a_aff = uniform(wave_min(a.alpha[0]));
+            double s1 = 0.0, s2 = 0.0;
+            for (int s = 0; s <= kend; ++s) {      // chains from stage 0 up to stage N
+                const double i1 = lane_below<true>(s1, 0.0), i2 = lane_below<true>(s2, 0.0);
+                s1 = (j <= kend) ? i1 + a.s1 : i1;
+                s2 = (j <= kend) ? i2 + a.s2 : i2;
+            }
+            S1 = uniform(bcast(s1, kend));
+            S2 = uniform(bcast(s2, kend));
+        }
+        SUB_END(24);
+        double sigma_mu;
+        {
+            double S0 = mu * (double)m_total;
+            double mu_aff = fma(a_aff, fma(a_aff, S2, S1), S0) / (double)m_total;
+            if (mu_aff < 0.0) mu_aff = 0.0;
+            double ratio = mu_aff / mu;
+            double sigma = ratio * ratio * ratio;
+            sigma_mu = sigma * mu;
+        }
+        // ================= Bs: corrector and centring-only right-hand sides, substituted backwards =================
+        double o1[NX], o2[NX], kvo[2][NU] = {{0.0, 0.0}, {0.0, 0.0}};
+        {
+            BsIn<NH> bin = {};
+            BsOut t2 = {};
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { bin.x[i] = R.x[i]; t2.prb[i] = ro.prb[i]; t2.k0[i] = ro.K[0][i]; t2.k1[i] = ro.K[1][i]; }
+            bin.u[0] = R.u[0]; bin.u[1] = R.u[1];
+#pragma unroll
+            for (int jj = 0; jj < NZ; ++jj) { bin.v[jj] = R.v[jj]; bin.dva[jj] = R.dva[jj]; t2.gt1[jj] = t.rg[jj]; }
+#pragma unroll
+            for (int r = 0; r < M::R; ++r) { bin.ll[r] = R.ll[r]; bin.lu[r] = R.lu[r]; bin.tl[r] = R.tl[r]; bin.tu[r] = R.tu[r]; }
+            t2.ab = R.ab;
+            t2.l10 = (kj < N) ? ro.l10 : 0.0; t2.d0 = (kj < N) ? ro.d0 : 1.0; t2.d1 = (kj < N) ? ro.d1 : 1.0;
+            if (on) stage_Bs_compute<NH, ANY>(S, o, pc, sigma_mu, bin, t2, kr);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { o1[i] = 0.0; o2[i] = 0.0; }
+            if (kj == N) stage_Bs_rec<LAST>(S, t2, o1, o2, kvo);
+            for (int s = 0; s < N; ++s) {
+                double i1[NX], i2[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    i1[i] = lane_above<true>(o1[i], 0.0);
+                    i2[i] = lane_above<true>(o2[i], 0.0);
+                }
+                if (kj < N) {
+                    stage_Bs_rec<MID>(S, t2, i1, i2, kvo);
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { o1[i] = i1[i]; o2[i] = i2[i]; }
+                }
+            }
+        }
+        SUB_END(25);
+        // ================= F (both): corrector and centring-only steps, their lengths =================
+        double alpha1, alpha2;
+        double dvo[2][NZ], dpo[2][NX];
+        {
+            FIn<NH, 2> ld = {};
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                ld.x[i] = R.x[i]; ld.rb[i] = t.rb[i]; ld.kg[0][i] = ro.K[0][i]; ld.kg[1][i] = ro.K[1][i];
+                ld.pv[0][i] = o1[i]; ld.pv[1][i] = o2[i];
+            }
+            ld.u[0] = R.u[0]; ld.u[1] = R.u[1];
+            ld.kv[0][0] = kvo[0][0]; ld.kv[0][1] = kvo[0][1]; ld.kv[1][0] = kvo[1][0]; ld.kv[1][1] = kvo[1][1];
+#pragma unroll
+            for (int jj = 0; jj < NZ; ++jj) { ld.v[jj] = R.v[jj]; ld.dva[jj] = R.dva[jj]; }
+#pragma unroll
+            for (int r = 0; r < M::R; ++r) { ld.ll[r] = R.ll[r]; ld.lu[r] = R.lu[r]; ld.tl[r] = R.tl[r]; ld.tu[r] = R.tu[r]; }
+#pragma unroll
+            for (int i = 0; i < 15; ++i) ld.Pk[i] = Po[i];
+            ld.ab = R.ab;
+            double dxi[2][NX], dxo[2][NX];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { dxi[q][i] = 0.0; dxo[q][i] = 0.0; }
+            for (int s = 0; s <= kend; ++s) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) dxi[q][i] = lane_below<true>(dxo[q][i], 0.0);
+                    if (kj < N) {
+                        double du[NU];
+                        F_rec(C, ld.ab, ld.kg, ld.kv[q], ld.rb, dxi[q], du, dxo[q]);
+                    }
+                }
+            }
+            FAcc a = {{1.0, 1.0}, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int jj = 0; jj < NZ; ++jj) dvo[q][jj] = 0.0;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) dpo[q][i] = 0.0;
+            }
+            if (on) stage_F_compute<NH, ANY, 2, false>(S, o, pc, 0, sigma_mu, ld, dxi, a, kr, dvo, dpo);
+            alpha1 = uniform(wave_min(a.alpha[0]));
+            alpha2 = uniform(wave_min(a.alpha[1]));
+        }
+        SUB_END(26);
+        // ================= the step taken =================
+        const bool use2 = o.cond_pred_corr && (alpha1 < a_aff);
+        const double alpha = use2 ? alpha2 : alpha1;
+        ++qit;
+        ++done;
+#pragma unroll
+        for (int jj = 0; jj < NZ; ++jj) R.dv[jj] = use2 ? dvo[1][jj] : dvo[0][jj];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dpi[i] = use2 ? dpo[1][i] : dpo[0][i];
+        if (!(alpha > o.alpha_min)) {      // minimum step or NaN
+            add_total = qit;
+            add_sqp = 1;
+            n_status = MPCX_QP_FAILURE;
+            n_state = LS_OUT;
+            break;
+        }
+        sp.have = true;
+        sp.mode = use2 ? 2 : 1;
+        sp.sigma_mu = sigma_mu;
+        sp.alpha = alpha * fma(alpha, 0.9999999, (1.0 - alpha) * 0.99);
+        if (done >= max_iters) break;
+    }
+    // ---- the stage goes back to the workspace: the iterate and the pending step, where the sweeps expect them ----
+    if (on) {
+        const int sol = (sp.mode == 2) ? M::SOL2 : 0;
+#pragma unroll
+        for (int jj = 0; jj < NZ; ++jj) {
+            stw<ANY>(S, 0, M::V + jj, R.v[jj]);
+            stw<ANY>(S, 0, M::DVA + jj, R.dva[jj]);
+            *wsp(S, 0, M::DV + jj, 512u * (unsigned)sol) = R.dv[jj];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            stw<ANY>(S, 0, M::QPI + i, R.qpi[i]);
+            *wsp(S, 0, M::DPI + i, 512u * (unsigned)sol) = dpi[i];
+        }
+#pragma unroll
+        for (int r = 0; r < M::R; ++r) {
+            stw<ANY>(S, 0, M::LAML + r, R.ll[r]);
+            stw<ANY>(S, 0, M::LAMU + r, R.lu[r]);
+            stw<ANY>(S, 0, M::TL + r, R.tl[r]);
+            stw<ANY>(S, 0, M::TU + r, R.tu[r]);
+        }
+    }
+    lds_order();
+    if (j == 0) {
+        carry[BR_STATE] = (double)n_state; carry[BR_STATUS] = (double)n_status; carry[BR_ADD_TOTAL] = (double)add_total;
+        carry[BR_ADD_SQP] = (double)add_sqp; carry[BR_QIT] = (double)qit; carry[BR_HAVE] = sp.have ? 1.0 : 0.0;
+        carry[BR_MODE] = (double)sp.mode; carry[BR_SIGMA_MU] = sp.sigma_mu; carry[BR_ALPHA] = sp.alpha;
+        carry[BR_DONE] = (double)done;
+    }
+    lds_order();
+}
+
 // sweep L has no recursion: every stage is linearised at its own (new) state, which its lane
 // forms from the stage's own iterate and step exactly as the stage before would have
 template <int NH, bool ONE>
@@ -2133,13 +2491,6 @@ __device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, const mpcx_opts *o
 // does not influence any result.
 // ---------------------------------------------------------------------------
 
-enum LaneState {
-    LS_FETCH = 0,   // needs a problem
-    LS_LIN = 1,     // needs sweep L (new SQP iteration)
-    LS_QP = 2,      // inside the interior point: one iteration per tick
-    LS_OUT = 3,     // problem ended, results not written yet
-    LS_DONE = 4     // no problems left
-};
 
 // Write-out, fetch and sweep L ("service") run with few lanes each, so they are held
 // back until this many lanes wait for them (or no lane has interior-point work).
@@ -2154,7 +2505,7 @@ enum LaneState {
 template <int NH>
 __global__ void __launch_bounds__(64) __attribute__((disable_tail_calls))
 mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
-                int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots, unsigned deal)
+                int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots, unsigned deal, int burst_few)
 {
     const mpcx_opts &o = *op;
     typedef Map<NH> M;
@@ -2298,6 +2649,43 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             qp_it = qit;
             sp = s;
         }
+    };
+
+    // up to max_iters interior-point iterations of the problem of lane p in one go, its stages resident
+    // in the lanes' registers (N < 64); returns the iterations done
+    auto single_burst = [&](int p, int max_iters) -> int {
+        coop_sync();
+        Lane C;
+        PC<NH> pcc;
+        problem_of_lane<NH>(L, pc, (ldouble *)pc_lds, p, C, pcc);
+        const int have = __builtin_amdgcn_readlane((int)sp.have, p) != 0;
+        const int mode = __builtin_amdgcn_readlane(sp.mode, p);
+        const double sgm = bcast(sp.sigma_mu, p), alp = bcast(sp.alpha, p);
+        const int mt = __builtin_amdgcn_readlane(m_total, p);
+        const int qit0 = __builtin_amdgcn_readlane(qp_it, p);
+        if (max_iters > 0x7fff) max_iters = 0x7fff;
+        if (max_iters < 1) max_iters = 1;
+        coop_burst<NH>(COOP_PASS(C, pcc), op, (have << 8) | (mode & 255), sgm, alp, mt,
+                       (max_iters << 16) | (qit0 & 0xffff), ret);
+        ldouble *carry = ret - threadIdx.x + 5 * 64;
+        const int n_state = (int)uniform(carry[BR_STATE]), n_status = (int)uniform(carry[BR_STATUS]),
+                  add_total = (int)uniform(carry[BR_ADD_TOTAL]), add_sqp = (int)uniform(carry[BR_ADD_SQP]),
+                  qit = (int)uniform(carry[BR_QIT]), done = (int)uniform(carry[BR_DONE]);
+        Step s;
+        s.have = uniform(carry[BR_HAVE]) != 0.0;
+        s.mode = (int)uniform(carry[BR_MODE]);
+        s.sigma_mu = uniform(carry[BR_SIGMA_MU]);
+        s.alpha = uniform(carry[BR_ALPHA]);
+        if ((int)threadIdx.x == p) {
+            state = n_state;
+            if (n_status >= 0) status = n_status;
+            qp_total += add_total;
+            sqp_it += add_sqp;
+            qp_it = qit;
+            sp = s;
+        }
+        STAMP_N(12, 64 * (done + (n_state != LS_QP ? 1 : 0)));
+        return done;
     };
 
     // Regions: `slots` per wavefront, behind the stage records.  A problem that the wavefront will
@@ -2533,7 +2921,10 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         // ---- few problems left: one interior-point iteration of each, the wavefront on one problem
         const unsigned long long qp_mask = __ballot(state == LS_QP);
         if (__popcll(qp_mask) <= coop_max || L.region != 0) {
-            for (unsigned long long rest = qp_mask; rest != 0; rest &= rest - 1) single_qp(__ffsll((long long)rest) - 1);
+            for (unsigned long long rest = qp_mask; rest != 0; rest &= rest - 1) {
+                if (N < 64 && burst_few > 0) (void)single_burst(__ffsll((long long)rest) - 1, burst_few);
+                else single_qp(__ffsll((long long)rest) - 1);
+            }
             coop_sync();      // every single-problem sweep starts with one; this one is for the other mode
             STAMP(11, state != LS_DONE);
             continue;
@@ -2633,12 +3024,20 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                 if (k < 1) k = 1;
                 budget -= k;
                 if (threadIdx.x == 0 && best >= 1000) MARK(23);
-                for (int t = 0; t < k; ++t) {
+                for (int t = 0; t < k;) {
                     const int st = __builtin_amdgcn_readlane(state, p);
-                    if (st == LS_QP) single_qp(p);
-                    else if (st == LS_LIN) {
+                    if (st == LS_QP) {
+                        if (N < 64 && burst_few > 0) {
+                            const int d = single_burst(p, k - t);
+                            t += (d > 0) ? d : 1;
+                        } else {
+                            single_qp(p);
+                            ++t;
+                        }
+                    } else if (st == LS_LIN) {
                         single_L(p);
                         if ((int)threadIdx.x == p) after_L();
+                        ++t;
                     } else break;
                 }
             }
@@ -2733,6 +3132,11 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
         }
     }
     if (const char *e = getenv("MPCX_SLOTS")) { int v = atoi(e); if (v >= 0 && v <= slots) slots = v; }   // fewer only
+    // interior-point iterations a problem gets in one go while its wavefront takes its few problems in turn,
+    // the stages resident in registers (N < 64); 0 = the separate sweeps, one iteration at a time (diagnostic)
+    int burst_few = 8;
+    if (const char *e = getenv("MPCX_BURST")) { int v = atoi(e); if (v >= 0 && v <= 1024) burst_few = v; }
+
     int svc_min = MPCX_SERVICE_MIN;
     if (const char *e = getenv("MPCX_SVC_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) svc_min = v; }
     if (coop_max < 0 || coop_max > 64) return hipErrorInvalidValue;
@@ -2763,12 +3167,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     }
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few); break;
 #else
     default: return hipErrorInvalidValue;
 #endif

@@ -48,9 +48,9 @@ mark_slots = [20, 21, 22, 23]
 marks_raw = cyc[:, mark_slots].copy()
 cyc[:, mark_slots] = 0
 # parts of the single-problem sweeps (already contained in slots 12..15)
-sub_slots = {16: "    B0 loads + rows", 17: "    B0 reductions", 18: "    B0 Riccati pipeline", 19: "    B0 stores",
-             24: "    Bs loads + rows", 25: "    Bs pipeline + stores", 26: "    F loads + pipeline",
-             27: "    F rows + reductions", 28: "    fence before B0", 29: "    problem parameters",
+# bursts (N < 64): slot 12 holds whole bursts, lanes-sum / 64 = iterations + QP ends
+sub_slots = {16: "    burst: B0 rows + reductions", 17: "    burst: Riccati pipeline", 24: "    burst: F affine", 25: "    burst: Bs", 26: "    burst: F both",
+             27: "    burst: loads at the start", 28: "    fence before B0", 29: "    problem parameters",
              30: "    B0 call"}
 sub_raw = {k: cyc[used, k].sum() for k in sub_slots}
 cyc[:, list(sub_slots)] = 0
