@@ -58,6 +58,10 @@ def parse_args(argv=None):
     ap.add_argument("--lib", default=None, help="another build of the library (diagnostic builds)")
     ap.add_argument("--cpu-sample", type=int, default=262144, help="problems timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-to-host timing of the batch")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="control-flow rehearsal of the multi-rank paths where only one GPU is there: every rank "
+                         "uses GPU 0 and the collectives run over gloo on host copies (RCCL refuses two ranks on "
+                         "one device); the line says so and is no measurement")
     return ap.parse_args(argv)
 
 
@@ -66,6 +70,8 @@ def launch_ranks(args):
     process has made any GPU call (counting devices does not initialise one)."""
     import torch
     have = torch.cuda.device_count()
+    if args.rehearse_on_one_gpu:
+        have = args.gpus if have >= 1 else 0
     if have < args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible to this process; refusing to "
                          f"report a {args.gpus}-GPU number from fewer devices")
@@ -144,14 +150,22 @@ def main():
                          f"(or without a launcher, and it starts the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    rehearsal = args.rehearse_on_one_gpu and world > 1
+    if rehearsal:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: no GPU {local_rank} (visible: {torch.cuda.device_count()})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == world
+    # tensors that go through a collective: device tensors under RCCL, host copies in a rehearsal
+    coll = (lambda t: t.cpu()) if rehearsal else (lambda t: t)
 
     lib = _lib.load_library(args.lib)
     opts = _lib.default_opts(lib)
@@ -205,7 +219,7 @@ def main():
             # the one exchange of the path: every rank's slice of the results to rank 0, over RCCL
             g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             g0.record(stream)
-            gathered = gather_to_root(out, B_total, dst=0)
+            gathered = gather_to_root({k: coll(v) for k, v in out.items()} if rehearsal else out, B_total, dst=0)
             g1.record(stream)
             if timed:
                 gather_ev.append((g0, g1))
@@ -256,12 +270,13 @@ def main():
     per_rank = torch.tensor([own_elapsed * 1e3 / max(args.steps, 1), kernel_ms, float(qp_it.max()) if B else 0.0],
                             dtype=torch.float64, device=dev)
     if world > 1:
-        mx = tot[:1].clone()
+        mx = coll(tot[:1].clone())
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tot[1:].clone()
+        sm = coll(tot[1:].clone())
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed = float(mx[0])
         n_conv_all, fl_all, fl_dense_all, B_all, qp_all = (float(v) for v in sm)
+        per_rank = coll(per_rank)
         pr = [torch.empty_like(per_rank) for _ in range(world)]
         dist.all_gather(pr, per_rank)
         per_rank_rows = [[float(v) for v in t] for t in pr]
@@ -273,7 +288,7 @@ def main():
         # the gathered arrays are the whole batch in the caller's order
         assert gathered["status"].shape[0] == B_total
         assert int((gathered["status"] == 0).sum()) == int(n_conv_all)
-        assert torch.equal(gathered["X"][:B], out["X"])
+        assert torch.equal(gathered["X"][:B], coll(out["X"]))
 
     if rank != 0:
         if world > 1:
@@ -312,6 +327,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
+        **({"rehearsal": "all ranks on one GPU, collectives over gloo: control flow only, not a measurement"} if rehearsal else {}),
         "config": {"workload": what,
                    "problems_per_gpu": B if not strong else None, "N": N, "problems_total": int(B_all),
                    "converged_fraction": n_conv_all / B_all if B_all else 0.0,

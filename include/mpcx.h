@@ -89,9 +89,9 @@ typedef struct mpcx_opts {
     int32_t max_sqp_iter;   /* nlp_solver_max_iter = 200 (core_solver.py:246)        */
     int32_t max_qp_iter;    /* qp_solver_iter_max  = 50  (core_solver.py:251)        */
     double  tol_stat, tol_eq, tol_ineq, tol_comp;   /* tol = 1e-3 (core_solver.py:252) */
-    double  qp_tol_stat, qp_tol_eq, qp_tol_ineq, qp_tol_comp;
+    double  qp_tol_stat, qp_tol_eq, qp_tol_ineq, qp_tol_comp;   /* defaults 1e-6, 1e-8, 1e-8, 1e-6 */
     double  lm;             /* levenberg_marquardt = 1e-2 (core_solver.py:247)       */
-    int32_t lm_scale_by_h;  /* 0: add lm as is; 1: add h*lm on stages < N            */
+    int32_t lm_scale_by_h;  /* 1 (default): add h*lm on stages < N, lm on stage N; 0: lm as is */
     int32_t cond_pred_corr; /* conditional Mehrotra corrector on/off                 */
     double  mu0;            /* initial barrier parameter                             */
     double  thr0;           /* slack floor of the cold start                         */

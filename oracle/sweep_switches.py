@@ -39,7 +39,7 @@ PINS = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_pins.json
 HPIPM_TOL = dict(qp_tol_stat=1e-6, qp_tol_eq=1e-8, qp_tol_ineq=1e-8, qp_tol_comp=1e-8)
 
 SETTINGS = [
-    ("defaults", {}, 0),
+    ("starting point: lm unscaled, QP tolerances = NLP tolerance 1e-3", {}, 0),
     ("lm_scale_by_h = 1", dict(lm_scale_by_h=1), 0),
     ("mu0 = 1", dict(mu0=1.0), 0),
     ("mu0 = 100", dict(mu0=100.0), 0),
@@ -60,8 +60,39 @@ SETTINGS = [
 ]
 
 
+# second table: the same switches around lm_scale_by_h = 1 (the setting the first table favours)
+HPIPM_TOL_LM = dict(lm_scale_by_h=1, **HPIPM_TOL)
+AROUND_LM = [
+    ("lm_scale_by_h = 1", dict(lm_scale_by_h=1), 0),
+    ("+ mu0 = 1", dict(lm_scale_by_h=1, mu0=1.0), 0),
+    ("+ mu0 = 100", dict(lm_scale_by_h=1, mu0=100.0), 0),
+    ("+ thr0 = 1e-2", dict(lm_scale_by_h=1, thr0=1e-2), 0),
+    ("+ thr0 = 1", dict(lm_scale_by_h=1, thr0=1.0), 0),
+    ("+ QP tolerances 1e-6 / 1e-8", HPIPM_TOL_LM, 0),
+    ("+ QP tolerances 1e-4", dict(lm_scale_by_h=1, qp_tol_stat=1e-4, qp_tol_eq=1e-4, qp_tol_ineq=1e-4, qp_tol_comp=1e-4), 0),
+    ("+ alpha_min = 1e-12", dict(lm_scale_by_h=1, alpha_min=1e-12), 0),
+    ("+ cond_pred_corr = 0", dict(lm_scale_by_h=1, cond_pred_corr=0), 0),
+    ("+ stage-0 corridor + obstacle rows", dict(lm_scale_by_h=1), 2),
+    ("+ lm = 1e-3", dict(lm_scale_by_h=1, lm=1e-3), 0),
+    ("+ lm = 1e-1", dict(lm_scale_by_h=1, lm=1e-1), 0),
+    ("+ QP tolerances 1e-6 / 1e-8 / 1e-8 / 1e-6 (ADOPTED: the library's defaults)",
+     dict(lm_scale_by_h=1, qp_tol_stat=1e-6, qp_tol_eq=1e-8, qp_tol_ineq=1e-8, qp_tol_comp=1e-6), 0),
+    ("+ NLP tol 1e-4 (tighter than the reference's)", dict(lm_scale_by_h=1, tol_stat=1e-4, tol_eq=1e-4, tol_ineq=1e-4, tol_comp=1e-4,
+                                                          qp_tol_stat=1e-4, qp_tol_eq=1e-4, qp_tol_ineq=1e-4, qp_tol_comp=1e-4), 0),
+    ("+ NLP tol 1e-6 (how far the recorded numbers are from the converged solution)",
+     dict(lm_scale_by_h=1, tol_stat=1e-6, tol_eq=1e-6, tol_ineq=1e-6, tol_comp=1e-6,
+          qp_tol_stat=1e-6, qp_tol_eq=1e-6, qp_tol_ineq=1e-6, qp_tol_comp=1e-6), 0),
+    ("defaults at NLP tol 1e-6", dict(tol_stat=1e-6, tol_eq=1e-6, tol_ineq=1e-6, tol_comp=1e-6,
+                                      qp_tol_stat=1e-6, qp_tol_eq=1e-6, qp_tol_ineq=1e-6, qp_tol_comp=1e-6), 0),
+]
+
+
 def opts_with(changes):
     o = oracle_lib.default_opts()
+    # both tables are relative to the setting the restatement started from: Levenberg-Marquardt term
+    # unscaled, QP stopped at the NLP tolerance (the library's defaults today are the adopted setting)
+    o.lm_scale_by_h = 0
+    o.qp_tol_stat = o.qp_tol_eq = o.qp_tol_ineq = o.qp_tol_comp = 1e-3
     for k, v in changes.items():
         assert hasattr(o, k), k
         setattr(o, k, v)
@@ -115,6 +146,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="8 grid poses, 2 000 benchmark problems")
     ap.add_argument("--threads", type=int, default=min(8, os.cpu_count() or 1))
+    ap.add_argument("--around-lm", action="store_true", help="the second table: switches around lm_scale_by_h = 1")
     args = ap.parse_args()
     n_head = 2000 if args.quick else 20000
     lib = oracle_lib.load(oracle_lib.ORACLE_FAST_SO if os.path.exists(oracle_lib.ORACLE_FAST_SO) else oracle_lib.ORACLE_SO)
@@ -122,7 +154,7 @@ def main():
     print("| setting | max abs diff to the 28 recorded numbers | line: gap, SQP / IP it. | E_to_F: gap, SQP / IP it. | grid ok | segments ok | B_to_C terminal faces | benchmark status mix 0/1/2/3/4 | converged | mean IP it. | mean SQP it. |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")
     t0 = time.time()
-    for name, changes, stage0 in SETTINGS:
+    for name, changes, stage0 in (AROUND_LM if args.around_lm else SETTINGS):
         if stage0:
             os.environ["MPCX_ORACLE_STAGE0_ROWS"] = str(stage0)
         else:

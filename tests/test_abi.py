@@ -34,7 +34,8 @@ def test_struct_layout_and_defaults():
     o = _lib.default_opts()
     assert C.sizeof(_lib.MpcxOpts) == 136 and C.sizeof(_lib.MpcxBatch) == 40 and C.sizeof(_lib.MpcxResult) == 56
     assert (o.max_sqp_iter, o.max_qp_iter, o.tol_stat, o.lm) == (200, 50, 1e-3, 1e-2)   # core_solver.py:246-252
-    assert (o.qp_tol_comp, o.mu0, o.thr0, o.cond_pred_corr, o.rti, o.max_obs) == (1e-3, 10.0, 0.1, 1, 0, -1)
+    assert (o.qp_tol_stat, o.qp_tol_eq, o.qp_tol_ineq, o.qp_tol_comp, o.lm_scale_by_h) == (1e-6, 1e-8, 1e-8, 1e-6, 1)
+    assert (o.mu0, o.thr0, o.cond_pred_corr, o.rti, o.max_obs) == (10.0, 0.1, 1, 0, -1)
 
 
 def test_oracle_and_library_share_defaults(oracle):

@@ -144,6 +144,17 @@ def test_synthetic_obstacle_batch_matches_oracle(oracle, B):
         assert (ref["status"] == 0).any()
 
 
+def test_reachable_batch_matches_oracle(oracle):
+    """The benchmark's third workload: goals reached by an admissible input sequence, so most
+    problems converge and need tens of interior-point iterations (ageing, bursts, regions)."""
+    from mpc_amd.synthetic import reachable_batch
+    packed = reachable_batch(3000)
+    gpu = _lib.solve_packed(packed)
+    ref = oracle.solve_packed(packed)
+    cases.assert_same_solution(gpu, ref, "reachable B=3000")
+    assert (ref["status"] == 0).mean() > 0.9
+
+
 def test_scenarios_match_oracle(oracle):
     names = list(cases.SCENARIOS)
     egos, sims = zip(*(cases.make_scenario(n) for n in names))

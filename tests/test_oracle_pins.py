@@ -2,8 +2,12 @@
 (tests/golden/reference_pins.json: values transcribed from the reference's
 docs/*.npy result files, which numpy's safe loader refuses to open).
 
-Tolerance 1e-3 absolute: the reference solves with acados tol = 1e-3
-(core_solver.py:252), so two correct solvers agree to about that.
+Value pins (first / last rows of `line` and `E_to_F`): 1e-6 absolute, the bar the
+comparison with acados is meant to meet and the resolution of the recorded numbers
+(6 decimals).  The reference solves with tol = 1e-3 (core_solver.py:252), so this only
+holds because the restatement follows the same iterate path: two SQP iterations, each QP
+solved tightly (oracle/sweep_switches.py shows what moves it).  Active faces and
+saturation values of the other segments come from an older cost: 1e-4.
 """
 import json
 import os
@@ -20,6 +24,7 @@ import cases
 HERE = os.path.dirname(os.path.abspath(__file__))
 PINS = json.load(open(os.path.join(HERE, "golden", "reference_pins.json")))
 TOL = PINS["tolerance"]
+FACE_TOL = PINS["face_tolerance"]
 
 
 def _solve(name, oracle):
@@ -44,12 +49,12 @@ def test_active_faces_and_saturation(oracle):
     status, r = _solve("B_to_C", oracle)
     pin = PINS["B_to_C"]
     assert status == 0 and r["x"].shape[0] == pin["N"] + 1
-    assert abs(r["x"][-1, 2] - pin["xN_theta"]) < TOL      # terminal heading on its +eps face
-    assert abs(r["x"][-1, 3] - pin["xN_v"]) < TOL          # terminal speed on its -eps face
-    assert abs(r["x"][-1, 4] - pin["xN_delta"]) < TOL
-    assert abs(np.abs(r["x"][:, 4]).max() - pin["steering_saturates"]) < TOL
+    assert abs(r["x"][-1, 2] - pin["xN_theta"]) < FACE_TOL      # terminal heading on its +eps face
+    assert abs(r["x"][-1, 3] - pin["xN_v"]) < FACE_TOL          # terminal speed on its -eps face
+    assert abs(r["x"][-1, 4] - pin["xN_delta"]) < FACE_TOL
+    assert abs(np.abs(r["x"][:, 4]).max() - pin["steering_saturates"]) < FACE_TOL
     status, r = _solve("D_to_E", oracle)
-    assert status == 0 and abs(np.abs(r["x"][:, 4]).max() - 0.5) < TOL
+    assert status == 0 and abs(np.abs(r["x"][:, 4]).max() - 0.5) < FACE_TOL
     status, r = _solve("A_to_B", oracle)
     assert status == 0 and r["x"][0, 2] == PINS["A_to_B"]["x0_theta"]   # +pi stored as -pi, on the bound
 
