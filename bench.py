@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X vector FP64: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+HBM_ACHIEVABLE_MIX_GBS = 5270.0
 HBM_PEAK_GBS = 8000.0
 
 
@@ -266,6 +267,9 @@ def main():
     fl = flops.flops_from_stats(stats, N, sparse=True)
     assert fl_dense == flops.algorithmic_flops(status, sqp_it, qp_it, N)
 
+    conv = status == 0
+    fl_conv = flops.algorithmic_flops(status[conv], sqp_it[conv], qp_it[conv], N, sparse=True)
+
     tot = torch.tensor([elapsed, float(n_conv), fl, fl_dense, float(B), float(stats[6])], dtype=torch.float64, device=dev)
     per_rank = torch.tensor([own_elapsed * 1e3 / max(args.steps, 1), kernel_ms, float(qp_it.max()) if B else 0.0],
                             dtype=torch.float64, device=dev)
@@ -351,10 +355,16 @@ def main():
             "flops_per_launch": fl, "flops_constants": flops.constants(sparse=True),
             "flops_per_launch_dense_count": fl_dense, "flops_constants_dense_count": flops.constants(sparse=False),
             "frac_dense_count": (fl_dense / secs / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if secs > 0 else 0.0,
+            # the same fraction counting only the work of the problems that converged (rank 0's batch)
+            "converged_only_flops_frac": (fl_conv / secs / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if secs > 0 else 0.0,
             "traffic": traffic, "traffic_source": traffic_src,
             "traffic_GBs": traffic / secs / 1e9 if traffic and secs > 0 else None,
             "hbm_peak_GBs": HBM_PEAK_GBS,
             "frac_of_hbm_peak": traffic / secs / 1e9 / HBM_PEAK_GBS if traffic and secs > 0 else None,
+            # against what this load/store mix (96 loads + 35 stores of 512 B per stage visit) reaches with no
+            # arithmetic at all: profiles/micro/stream_rw.hip, profiles/r01_micro_stream_rw.txt
+            "achievable_GBs_this_mix": HBM_ACHIEVABLE_MIX_GBS,
+            "frac_of_achievable": traffic / secs / 1e9 / HBM_ACHIEVABLE_MIX_GBS if traffic and secs > 0 else None,
             "algorithmic_bytes_per_launch": io_bytes,
             "traffic_over_algorithmic_bytes": traffic / io_bytes if traffic and io_bytes else None,
             "kernel": "mpcx_sqp_kernel<1>" if args.obstacle else "mpcx_sqp_kernel<0>", "kernel_ms": kernel_ms,

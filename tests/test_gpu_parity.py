@@ -209,6 +209,20 @@ def test_sweep_modes_match_oracle(oracle, monkeypatch, duration, lanes):
     cases.assert_same_solution(gpu, ref, f"N={packed.N} lanes={lanes}")
 
 
+@pytest.mark.parametrize("burst", ["0", "1", "3", "8"])
+def test_burst_lengths_leave_no_trace(oracle, monkeypatch, burst):
+    """Single-problem iterations run back to back with the stages kept in registers (bursts of
+    1, 3, 8 iterations) or as four sweeps each (0): the same bits as the oracle every way, on a
+    batch small enough to start in single-problem mode and on one large enough for its old
+    problems to be aged into it."""
+    monkeypatch.setenv("MPCX_BURST", burst)
+    for B in (48, 3000):
+        packed = synthetic_batch(B, seed=77 + B)
+        gpu = _lib.solve_packed(packed)
+        ref = oracle.solve_packed(packed)
+        cases.assert_same_solution(gpu, ref, f"burst={burst} B={B}")
+
+
 @pytest.mark.parametrize("lanes", [None, 3, 20, 64])
 def test_rti_server_matches_oracle(oracle, monkeypatch, lanes):
     """Three receding-horizon ticks of a fleet: what the device solves each tick equals the
