@@ -1118,7 +1118,20 @@ DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
 // every read of the inputs precedes the first write of the outputs)
 struct RicOut { double prb[NX], l10, d0, d1, K[NU][NX], kv[NU]; };
 
-template <int KIND>
+// feed-forward of a stage from the input part (m0, m1) of its right-hand side: -(L D L')^-1 m
+DEV void feed_forward(double l10, double d0, double d1, double m0, double m1, double *kv)
+{
+    double y0 = m0;
+    double y1 = fma(-l10, y0, m1);
+    double z0 = y0 * d0, z1 = y1 * d1;
+    double s0 = fma(-l10, z1, z0);
+    kv[0] = -s0;
+    kv[1] = -z1;
+}
+
+// FF = false: kv receives (m0, m1) instead of the feed-forward, which the caller forms with
+// feed_forward() when it needs it (the lane pipelines need it once, after their last step)
+template <int KIND, bool FF = true>
 DEV void stage_B0_ric(const Lane &L, const B0Out &in, const double *Pn, const double *pn, double *Po, double *po,
                       RicOut &ro)
 {
@@ -1202,14 +1215,8 @@ DEV void stage_B0_ric(const Lane &L, const B0Out &in, const double *Pn, const do
 #pragma unroll
         for (int j = 0; j < NZ; ++j) m[j] = in.gt[j];
         add_BAt(L, in.ab, w, m);
-        {
-            double y0 = m[0];
-            double y1 = fma(-l10, y0, m[1]);
-            double z0 = y0 * d0, z1 = y1 * d1;
-            double s0 = fma(-l10, z1, z0);
-            ro.kv[0] = -s0;
-            ro.kv[1] = -z1;
-        }
+        if (FF) feed_forward(l10, d0, d1, m[0], m[1], ro.kv);
+        else { ro.kv[0] = m[0]; ro.kv[1] = m[1]; }
 #pragma unroll
         for (int i = 0; i < NX; ++i) po[i] = fma(Kg[1][i], m[1], fma(Kg[0][i], m[0], m[NU + i]));
         // P(k) = M_xx + M_xu K
@@ -1398,7 +1405,7 @@ DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
 
 // Bs, recursion part of a stage: pn1 / pn2 hold p(k+1) of the two systems on entry, p(k) on
 // return; kvo[s] = feed-forward of system s
-template <int KIND>
+template <int KIND, bool FF = true>
 DEV void stage_Bs_rec(const Lane &L, const BsOut &in, double *pn1, double *pn2, double (*kvo)[NU])
 {
     if (KIND == LAST) {
@@ -1415,12 +1422,8 @@ DEV void stage_Bs_rec(const Lane &L, const BsOut &in, double *pn1, double *pn2, 
 #pragma unroll
             for (int j = 0; j < NZ; ++j) m[j] = gt[j];
             add_BAt(L, in.ab, w, m);
-            double y0 = m[0];
-            double y1 = fma(-in.l10, y0, m[1]);
-            double z0 = y0 * in.d0, z1 = y1 * in.d1;
-            double s0 = fma(-in.l10, z1, z0);
-            kvo[sidx][0] = -s0;
-            kvo[sidx][1] = -z1;
+            if (FF) feed_forward(in.l10, in.d0, in.d1, m[0], m[1], kvo[sidx]);
+            else { kvo[sidx][0] = m[0]; kvo[sidx][1] = m[1]; }
 #pragma unroll
             for (int i = 0; i < NX; ++i) pn[i] = fma(in.k1[i], m[1], fma(in.k0[i], m[0], m[NU + i]));
         }
@@ -1481,6 +1484,23 @@ DEV void ratio_min(double val, double step, double &num, double &den)
     const bool c = (step < 0.0) && (val * den < num * (-step));
     num = c ? val : num;
     den = c ? -step : den;
+}
+
+// A copy of x the compiler cannot see through.  The lane pipelines below run some hundred steps on a
+// few operands while the rest of the stage waits in the accumulator registers; taking the operands
+// through this just before the loop gives them live ranges of their own, which the register allocator
+// then keeps in vector registers for the length of the loop (instead of reading them back every step).
+DEV double fresh(double x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+DEV void fresh_ab(AB &ab)
+{
+    ab.a02 = fresh(ab.a02); ab.a03 = fresh(ab.a03); ab.a04 = fresh(ab.a04); ab.a12 = fresh(ab.a12);
+    ab.a13 = fresh(ab.a13); ab.a14 = fresh(ab.a14); ab.a23 = fresh(ab.a23); ab.a24 = fresh(ab.a24);
+    ab.b00 = fresh(ab.b00); ab.b10 = fresh(ab.b10); ab.b20 = fresh(ab.b20); ab.b01 = fresh(ab.b01);
+    ab.b11 = fresh(ab.b11); ab.b21 = fresh(ab.b21);
 }
 
 // forward recursion of one stage: du = kv + K dx, dxn = A dx + B du + rb
@@ -1990,8 +2010,9 @@ __device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, const mpcx_
         for (int i = 0; i < 15; ++i) Pi[i] = lane_above<ONE>(Po[i], cP[i]);
 #pragma unroll
         for (int i = 0; i < NX; ++i) pi[i] = lane_above<ONE>(po[i], cp[i]);
-        if (kj < N) stage_B0_ric<MID>(S, t, Pi, pi, Po, po, ro);
+        if (kj < N) stage_B0_ric<MID, false>(S, t, Pi, pi, Po, po, ro);
     }
+    if (kj < N) feed_forward(ro.l10, ro.d0, ro.d1, ro.kv[0], ro.kv[1], ro.kv);
     SUB_END(18);
     if (j == 0) {
 #pragma unroll
@@ -2056,10 +2077,14 @@ __device__ __attribute__((noinline)) void coop_Bs(COOP_PARAMS, const mpcx_opts *
                 i2[i] = lane_above<ONE>(o2[i], c2[i]);
             }
             if (kj < N) {
-                stage_Bs_rec<MID>(S, t, i1, i2, kvo);
+                stage_Bs_rec<MID, false>(S, t, i1, i2, kvo);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) { o1[i] = i1[i]; o2[i] = i2[i]; }
             }
+        }
+        if (kj < N) {
+            feed_forward(t.l10, t.d0, t.d1, kvo[0][0], kvo[0][1], kvo[0]);
+            feed_forward(t.l10, t.d0, t.d1, kvo[1][0], kvo[1][1], kvo[1]);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) { c1[i] = bcast(o1[i], 0); c2[i] = bcast(o2[i], 0); }
@@ -2203,12 +2228,11 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
         const int kend = N;
         const double Rg = uniform(wave_max(t.ng)), Rb = uniform(wave_max(t.nb)), Rd = uniform(wave_max(t.nd)),
                      Rm = uniform(wave_max(t.nm));
-        double sum = 0.0;
-        for (int s = 0; s <= kend; ++s) {      // the complementarity sum: a chain from stage N down to stage 0
-            const double in = lane_above<true>(sum, 0.0);
-            sum = (j <= kend) ? in + t.ssum : in;
-        }
-        const double mu = uniform(bcast(sum, 0) / (double)m_total);
+        // The complementarity sum is a chain from stage N down to stage 0, 0 + s(N) + s(N-1) + ...; it rides
+        // along with the Riccati pipeline below, which hands values down the lanes in the same direction.
+        // (lanes without a stage hold s = +0 and hand down +0; no partial sum is ever -0, so adding their
+        // zero changes nothing)
+        double sum = 0.0 + t.ssum;
         SUB_END(16);
         double Po[15], po[NX];
         RicOut ro = {};
@@ -2236,8 +2260,11 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             for (int i = 0; i < 15; ++i) Pi[i] = lane_above<true>(Po[i], 0.0);
 #pragma unroll
             for (int i = 0; i < NX; ++i) pi[i] = lane_above<true>(po[i], 0.0);
-            if (kj < N) stage_B0_ric<MID>(S, t, Pi, pi, Po, po, ro);
+            sum = lane_above<true>(sum, 0.0) + t.ssum;
+            if (kj < N) stage_B0_ric<MID, false>(S, t, Pi, pi, Po, po, ro);
         }
+        if (kj < N) feed_forward(ro.l10, ro.d0, ro.d1, ro.kv[0], ro.kv[1], ro.kv);
+        const double mu = uniform(bcast(sum, 0) / (double)m_total);
         SUB_END(17);
         // ================= F (affine): predictor step, its length, centring sums =================
         double a_aff, S1, S2;
@@ -2255,6 +2282,10 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             double dxi[1][NX], dxo[1][NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) { dxi[0][i] = 0.0; dxo[0][i] = 0.0; }
+            fresh_ab(ld.ab);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { ld.kg[0][i] = fresh(ld.kg[0][i]); ld.kg[1][i] = fresh(ld.kg[1][i]); ld.rb[i] = fresh(ld.rb[i]); }
+            ld.kv[0][0] = fresh(ld.kv[0][0]); ld.kv[0][1] = fresh(ld.kv[0][1]);
             for (int s = 0; s <= kend; ++s) {
 #pragma unroll
                 for (int i = 0; i < NX; ++i) dxi[0][i] = lane_below<true>(dxo[0][i], 0.0);
@@ -2273,9 +2304,8 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             a_aff = uniform(wave_min(a.alpha[0]));
             double s1 = 0.0, s2 = 0.0;
             for (int s = 0; s <= kend; ++s) {      // chains from stage 0 up to stage N
-                const double i1 = lane_below<true>(s1, 0.0), i2 = lane_below<true>(s2, 0.0);
-                s1 = (j <= kend) ? i1 + a.s1 : i1;
-                s2 = (j <= kend) ? i2 + a.s2 : i2;
+                s1 = lane_below<true>(s1, 0.0) + a.s1;
+                s2 = lane_below<true>(s2, 0.0) + a.s2;
             }
             S1 = uniform(bcast(s1, kend));
             S2 = uniform(bcast(s2, kend));
@@ -2308,6 +2338,12 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
 #pragma unroll
             for (int i = 0; i < NX; ++i) { o1[i] = 0.0; o2[i] = 0.0; }
             if (kj == N) stage_Bs_rec<LAST>(S, t2, o1, o2, kvo);
+            fresh_ab(t2.ab);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { t2.prb[i] = fresh(t2.prb[i]); t2.k0[i] = fresh(t2.k0[i]); t2.k1[i] = fresh(t2.k1[i]); }
+#pragma unroll
+            for (int jj = 0; jj < NZ; ++jj) { t2.gt1[jj] = fresh(t2.gt1[jj]); t2.gt2[jj] = fresh(t2.gt2[jj]); }
+            t2.l10 = fresh(t2.l10);
             for (int s = 0; s < N; ++s) {
                 double i1[NX], i2[NX];
 #pragma unroll
@@ -2316,10 +2352,14 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
                     i2[i] = lane_above<true>(o2[i], 0.0);
                 }
                 if (kj < N) {
-                    stage_Bs_rec<MID>(S, t2, i1, i2, kvo);
+                    stage_Bs_rec<MID, false>(S, t2, i1, i2, kvo);
 #pragma unroll
                     for (int i = 0; i < NX; ++i) { o1[i] = i1[i]; o2[i] = i2[i]; }
                 }
+            }
+            if (kj < N) {
+                feed_forward(t2.l10, t2.d0, t2.d1, kvo[0][0], kvo[0][1], kvo[0]);
+                feed_forward(t2.l10, t2.d0, t2.d1, kvo[1][0], kvo[1][1], kvo[1]);
             }
         }
         SUB_END(25);
@@ -2347,6 +2387,11 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int i = 0; i < NX; ++i) { dxi[q][i] = 0.0; dxo[q][i] = 0.0; }
+            fresh_ab(ld.ab);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { ld.kg[0][i] = fresh(ld.kg[0][i]); ld.kg[1][i] = fresh(ld.kg[1][i]); ld.rb[i] = fresh(ld.rb[i]); }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { ld.kv[q][0] = fresh(ld.kv[q][0]); ld.kv[q][1] = fresh(ld.kv[q][1]); }
             for (int s = 0; s <= kend; ++s) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
