@@ -961,7 +961,9 @@ DEV void stage_B0_head(const Lane &L, int k, const Step &sp, B0In<NH> &in, const
 
 // second half: rows, residuals, barrier Hessian, affine right-hand side.  vxn / qpin: updated
 // x-part of v and dynamics multiplier of stage k+1.
-template <int NH, int KIND, bool ST = true>
+// RC = true (stage resident in registers): in.til_ / in.tiu_ carry the reciprocals of the slacks from
+// sweep to sweep; they hold those of the slacks on entry and of the updated slacks on return
+template <int NH, int KIND, bool ST = true, bool RC = false>
 DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, const Step &sp, B0In<NH> &in,
                        const double *vxn, const double *qpin, B0Out &out, const KR &kr = KR{false, false})
 {
@@ -1007,7 +1009,7 @@ DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
             double jvo = jdot(r, jx, jy, vo);
             double rdl = (dlo - jvo) + t_l;
             double rdu = (jvo - dup) + t_u;
-            double til = MPCX_STORE_RECIP ? til_[r] : 1.0 / t_l, tiu = MPCX_STORE_RECIP ? tiu_[r] : 1.0 / t_u;
+            double til = (MPCX_STORE_RECIP || RC) ? til_[r] : 1.0 / t_l, tiu = (MPCX_STORE_RECIP || RC) ? tiu_[r] : 1.0 / t_u;
             double jda = jdot(r, jx, jy, dva);
             double rml, rmu;
             row_rm(sp.mode, sp.sigma_mu, jda, l_l, l_u, t_l, t_u, til, tiu, rdl, rdu, rml, rmu);
@@ -1051,6 +1053,7 @@ DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
             stw<KIND>(L, k, M::TIL + r, til);
             stw<KIND>(L, k, M::TIU + r, tiu);
         }
+        if (RC) { til_[r] = til; tiu_[r] = tiu; }
         double ql = fma(-l_l, rdl, ml) * til;
         double qu = fma(-l_u, rdu, mu_) * tiu;
         qrow[r] = ql - qu;
@@ -1351,7 +1354,7 @@ DEV void stage_Bs_load(const Lane &L, int k, BsIn<NH> &in, BsOut &out, const KR 
 }
 
 // Bs, row part of stage k: the two right-hand sides; out.gt1 holds the stationarity residual on entry
-template <int NH, int KIND>
+template <int NH, int KIND, bool RC = false>
 DEV void stage_Bs_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, double sigma_mu, const BsIn<NH> &in,
                           BsOut &out, const KR &kr = KR{false, false})
 {
@@ -1373,7 +1376,7 @@ DEV void stage_Bs_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, d
         double jv = jdot(r, jx, jy, v);
         double rdl = (dlo - jv) + tl[r];
         double rdu = (jv - dup) + tu[r];
-        double til = MPCX_STORE_RECIP ? til_[r] : 1.0 / tl[r], tiu = MPCX_STORE_RECIP ? tiu_[r] : 1.0 / tu[r];
+        double til = (MPCX_STORE_RECIP || RC) ? til_[r] : 1.0 / tl[r], tiu = (MPCX_STORE_RECIP || RC) ? tiu_[r] : 1.0 / tu[r];
         double jda = jdot(r, jx, jy, dva);
         // complementarity targets: corrector and centring-only
         const double ml = ll[r] * tl[r], mu_ = lu[r] * tu[r];
@@ -1586,7 +1589,7 @@ DEV void stage_F_load(const Lane &L, int k, FIn<NH, NS> &in, const KR &kr = KR{f
 
 // ST = false: nothing is stored; the steps of the stage come back in dvo[q][0..6] and (NS = 2) the
 // steps of the dynamics multiplier in dpo[q][0..4]
-template <int NH, int KIND, int NS, bool ST = true>
+template <int NH, int KIND, int NS, bool ST = true, bool RC = false>
 DEV void stage_F_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu,
                          FIn<NH, NS> &in, double (*dx)[NX], FAcc &a, const KR &kr = KR{false, false},
                          double (*dvo)[NZ] = nullptr, double (*dpo)[NX] = nullptr)
@@ -1639,7 +1642,7 @@ DEV void stage_F_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, in
         double jv = jdot(r, jx, jy, v);
         double rdl = (dlo - jv) + tl[r];
         double rdu = (jv - dup) + tu[r];
-        double til = MPCX_STORE_RECIP ? til_[r] : 1.0 / tl[r], tiu = MPCX_STORE_RECIP ? tiu_[r] : 1.0 / tu[r];
+        double til = (MPCX_STORE_RECIP || RC) ? til_[r] : 1.0 / tl[r], tiu = (MPCX_STORE_RECIP || RC) ? tiu_[r] : 1.0 / tu[r];
         const double ml = ll[r] * tl[r], mu_ = lu[r] * tu[r];
         double rml[NS], rmu[NS];
         if (NS == 1) { rml[0] = ml; rmu[0] = mu_; }
@@ -2179,7 +2182,7 @@ enum LaneState {
 
 enum { BR_STATE = 0, BR_STATUS, BR_ADD_TOTAL, BR_ADD_SQP, BR_QIT, BR_HAVE, BR_MODE, BR_SIGMA_MU, BR_ALPHA, BR_DONE, BR_N };
 static_assert(BR_N <= CY_N, "burst results fit the carry words");
-static_assert(MPCX_STORE_RECIP == 0, "the resident burst recomputes the slack reciprocals");
+static_assert(MPCX_STORE_RECIP == 0, "the resident burst keeps the slack reciprocals in registers itself");
 
 template <int NH>
 __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opts *op, int sp_have_mode,
@@ -2209,6 +2212,9 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
 #pragma unroll
     for (int i = 0; i < NX; ++i) dpi[i] = 0.0;
     if (on) stage_B0_load<NH, ANY>(S, 0, sp, R, dpi, kr);
+    // the reciprocals of the slacks stay in registers with the stage (the sweeps recompute them where needed)
+#pragma unroll
+    for (int r = 0; r < M::R; ++r) { R.til_[r] = 1.0 / R.tl[r]; R.tiu_[r] = 1.0 / R.tu[r]; }
     int n_state = LS_QP, n_status = -1, add_total = 0, add_sqp = 0, done = 0;
     SUB_BEGIN();
     SUB_END(27);
@@ -2222,7 +2228,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             qpin[i] = lane_above<true>(R.qpi[i], 0.0);
         }
         B0Out t = {};
-        if (on) stage_B0_tail<NH, ANY, false>(S, o, pc, 0, sp, R, vxn, qpin, t, kr);
+        if (on) stage_B0_tail<NH, ANY, false, true>(S, o, pc, 0, sp, R, vxn, qpin, t, kr);
 #pragma unroll
         for (int jj = 0; jj < NZ; ++jj) R.vo[jj] = R.v[jj];      // the iterate the next pending step starts from
         const int kend = N;
@@ -2277,7 +2283,10 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
 #pragma unroll
             for (int jj = 0; jj < NZ; ++jj) { ld.v[jj] = R.v[jj]; ld.dva[jj] = 0.0; }
 #pragma unroll
-            for (int r = 0; r < M::R; ++r) { ld.ll[r] = R.ll[r]; ld.lu[r] = R.lu[r]; ld.tl[r] = R.tl[r]; ld.tu[r] = R.tu[r]; }
+            for (int r = 0; r < M::R; ++r) {
+                ld.ll[r] = R.ll[r]; ld.lu[r] = R.lu[r]; ld.tl[r] = R.tl[r]; ld.tu[r] = R.tu[r];
+                ld.til_[r] = R.til_[r]; ld.tiu_[r] = R.tiu_[r];
+            }
             ld.ab = R.ab;
             double dxi[1][NX], dxo[1][NX];
 #pragma unroll
@@ -2298,7 +2307,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             double dvo[1][NZ];
 #pragma unroll
             for (int jj = 0; jj < NZ; ++jj) dvo[0][jj] = 0.0;
-            if (on) stage_F_compute<NH, ANY, 1, false>(S, o, pc, 0, 0.0, ld, dxi, a, kr, dvo, nullptr);
+            if (on) stage_F_compute<NH, ANY, 1, false, true>(S, o, pc, 0, 0.0, ld, dxi, a, kr, dvo, nullptr);
 #pragma unroll
             for (int jj = 0; jj < NZ; ++jj) R.dva[jj] = dvo[0][jj];
             a_aff = uniform(wave_min(a.alpha[0]));
@@ -2331,10 +2340,13 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
 #pragma unroll
             for (int jj = 0; jj < NZ; ++jj) { bin.v[jj] = R.v[jj]; bin.dva[jj] = R.dva[jj]; t2.gt1[jj] = t.rg[jj]; }
 #pragma unroll
-            for (int r = 0; r < M::R; ++r) { bin.ll[r] = R.ll[r]; bin.lu[r] = R.lu[r]; bin.tl[r] = R.tl[r]; bin.tu[r] = R.tu[r]; }
+            for (int r = 0; r < M::R; ++r) {
+                bin.ll[r] = R.ll[r]; bin.lu[r] = R.lu[r]; bin.tl[r] = R.tl[r]; bin.tu[r] = R.tu[r];
+                bin.til_[r] = R.til_[r]; bin.tiu_[r] = R.tiu_[r];
+            }
             t2.ab = R.ab;
             t2.l10 = (kj < N) ? ro.l10 : 0.0; t2.d0 = (kj < N) ? ro.d0 : 1.0; t2.d1 = (kj < N) ? ro.d1 : 1.0;
-            if (on) stage_Bs_compute<NH, ANY>(S, o, pc, sigma_mu, bin, t2, kr);
+            if (on) stage_Bs_compute<NH, ANY, true>(S, o, pc, sigma_mu, bin, t2, kr);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { o1[i] = 0.0; o2[i] = 0.0; }
             if (kj == N) stage_Bs_rec<LAST>(S, t2, o1, o2, kvo);
@@ -2378,7 +2390,10 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
 #pragma unroll
             for (int jj = 0; jj < NZ; ++jj) { ld.v[jj] = R.v[jj]; ld.dva[jj] = R.dva[jj]; }
 #pragma unroll
-            for (int r = 0; r < M::R; ++r) { ld.ll[r] = R.ll[r]; ld.lu[r] = R.lu[r]; ld.tl[r] = R.tl[r]; ld.tu[r] = R.tu[r]; }
+            for (int r = 0; r < M::R; ++r) {
+                ld.ll[r] = R.ll[r]; ld.lu[r] = R.lu[r]; ld.tl[r] = R.tl[r]; ld.tu[r] = R.tu[r];
+                ld.til_[r] = R.til_[r]; ld.tiu_[r] = R.tiu_[r];
+            }
 #pragma unroll
             for (int i = 0; i < 15; ++i) ld.Pk[i] = Po[i];
             ld.ab = R.ab;
@@ -2411,7 +2426,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
 #pragma unroll
                 for (int i = 0; i < NX; ++i) dpo[q][i] = 0.0;
             }
-            if (on) stage_F_compute<NH, ANY, 2, false>(S, o, pc, 0, sigma_mu, ld, dxi, a, kr, dvo, dpo);
+            if (on) stage_F_compute<NH, ANY, 2, false, true>(S, o, pc, 0, sigma_mu, ld, dxi, a, kr, dvo, dpo);
             alpha1 = uniform(wave_min(a.alpha[0]));
             alpha2 = uniform(wave_min(a.alpha[1]));
         }
