@@ -1409,8 +1409,10 @@ DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
 // Bs, recursion part of a stage: pn1 / pn2 hold p(k+1) of the two systems on entry, p(k) on
 // return; kvo[s] = feed-forward of system s
 template <int KIND, bool FF = true>
-DEV void stage_Bs_rec(const Lane &L, const BsOut &in, double *pn1, double *pn2, double (*kvo)[NU])
+DEV void stage_Bs_rec(const Lane &L, const BsOut &in, const double *pi1, const double *pi2, double *pn1, double *pn2,
+                      double (*kvo)[NU])
 {
+    // (pi1 / pi2 may be pn1 / pn2: every read of an input precedes the first write of the outputs)
     if (KIND == LAST) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) { pn1[i] = in.gt1[NU + i]; pn2[i] = in.gt2[NU + i]; }
@@ -1418,10 +1420,11 @@ DEV void stage_Bs_rec(const Lane &L, const BsOut &in, double *pn1, double *pn2, 
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
             double *pn = sidx ? pn2 : pn1;
+            const double *pin = sidx ? pi2 : pi1;
             const double *gt = sidx ? in.gt2 : in.gt1;
             double w[NX], m[NZ];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) w[i] = pn[i] + in.prb[i];
+            for (int i = 0; i < NX; ++i) w[i] = pin[i] + in.prb[i];
 #pragma unroll
             for (int j = 0; j < NZ; ++j) m[j] = gt[j];
             add_BAt(L, in.ab, w, m);
@@ -1454,7 +1457,7 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, do
     BsOut t;
     stage_Bs_rows<NH, KIND>(L, o, pc, k, sigma_mu, t);
     double kvo[2][NU];
-    stage_Bs_rec<KIND>(L, t, pn1, pn2, kvo);
+    stage_Bs_rec<KIND>(L, t, pn1, pn2, pn1, pn2, kvo);
     store_rec<NH, KIND>(L, k, KIND != LAST, KIND != FIRST, kvo, pn1, pn2);
 }
 
@@ -1883,6 +1886,27 @@ DEV double lane_below(double v, double edge)
     return __hiloint2double(hi, lo);
 }
 
+// The same for sweeps over several blocks of stages, where the lane at the end of the wavefront takes the
+// value the neighbouring block handed over.  `prev` is the destination of the previous step of the same
+// pipeline, started from the block's edge value: the move leaves the end lane of its destination alone, so
+// that lane holds the edge value throughout and the destination needs no copy of it each step.
+template <bool ZERO>
+DEV double lane_above_keep(double prev, double v)
+{
+    if (ZERO) return lane_above<true>(v, 0.0);
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(prev), __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(prev), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <bool ZERO>
+DEV double lane_below_keep(double prev, double v)
+{
+    if (ZERO) return lane_below<true>(v, 0.0);
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(prev), __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(prev), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // The maxima and minima over the stages do not depend on the order (the per-stage values are
 // never NaN: each starts from the identity and is updated by a comparison that a NaN fails), so
 // they are reduced by a DPP tree; lanes without a source take the identity.  The sums stay chains.
@@ -1980,10 +2004,11 @@ __device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, const mpcx_
     {
         // the sum is a chain from stage kend down to the block's first: the same pipeline as
         // the recursions (lanes above kend keep handing down the value the chain starts from)
-        const double start = sum;
+        // (they hold s = +0, and no partial sum is ever -0, so adding their zero changes nothing)
+        double in = sum;
         for (int s = 0; s <= kend; ++s) {
-            const double in = lane_above<ONE>(sum, start);
-            sum = (j <= kend) ? in + t.ssum : in;
+            in = lane_above_keep<ONE>(in, sum);
+            sum = in + t.ssum;
         }
         sum = bcast(sum, 0);
     }
@@ -2007,12 +2032,16 @@ __device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, const mpcx_
     for (int i = 0; i < 15; ++i) Po[i] = 0.0;
     if (kj == N) stage_B0_ric<LAST>(S, t, Po, po, Po, po, ro);
     const int steps = (N - k0 < 64) ? N - k0 : 64;       // stages below N in this block
+    double Pi[15], pi[NX];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) Pi[i] = cP[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) pi[i] = cp[i];
     for (int s = 0; s < steps; ++s) {
-        double Pi[15], pi[NX];
 #pragma unroll
-        for (int i = 0; i < 15; ++i) Pi[i] = lane_above<ONE>(Po[i], cP[i]);
+        for (int i = 0; i < 15; ++i) Pi[i] = lane_above_keep<ONE>(Pi[i], Po[i]);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) pi[i] = lane_above<ONE>(po[i], cp[i]);
+        for (int i = 0; i < NX; ++i) pi[i] = lane_above_keep<ONE>(pi[i], po[i]);
         if (kj < N) stage_B0_ric<MID, false>(S, t, Pi, pi, Po, po, ro);
     }
     if (kj < N) feed_forward(ro.l10, ro.d0, ro.d1, ro.kv[0], ro.kv[1], ro.kv);
@@ -2070,20 +2099,18 @@ __device__ __attribute__((noinline)) void coop_Bs(COOP_PARAMS, const mpcx_opts *
         double o1[NX], o2[NX], kvo[2][NU] = {{0.0, 0.0}, {0.0, 0.0}};
 #pragma unroll
         for (int i = 0; i < NX; ++i) { o1[i] = 0.0; o2[i] = 0.0; }
-        if (kj == N) stage_Bs_rec<LAST>(S, t, o1, o2, kvo);
+        if (kj == N) stage_Bs_rec<LAST>(S, t, o1, o2, o1, o2, kvo);
         const int steps = (N - k0 < 64) ? N - k0 : 64;
+        double i1[NX], i2[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { i1[i] = c1[i]; i2[i] = c2[i]; }
         for (int s = 0; s < steps; ++s) {
-            double i1[NX], i2[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                i1[i] = lane_above<ONE>(o1[i], c1[i]);
-                i2[i] = lane_above<ONE>(o2[i], c2[i]);
+                i1[i] = lane_above_keep<ONE>(i1[i], o1[i]);
+                i2[i] = lane_above_keep<ONE>(i2[i], o2[i]);
             }
-            if (kj < N) {
-                stage_Bs_rec<MID, false>(S, t, i1, i2, kvo);
-#pragma unroll
-                for (int i = 0; i < NX; ++i) { o1[i] = i1[i]; o2[i] = i2[i]; }
-            }
+            if (kj < N) stage_Bs_rec<MID, false>(S, t, i1, i2, o1, o2, kvo);
         }
         if (kj < N) {
             feed_forward(t.l10, t.d0, t.d1, kvo[0][0], kvo[0][1], kvo[0]);
@@ -2123,12 +2150,12 @@ __device__ __attribute__((noinline)) double coop_F(COOP_PARAMS, const mpcx_opts 
 #pragma unroll
         for (int q = 0; q < NS; ++q)
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { dxi[q][i] = 0.0; dxo[q][i] = 0.0; }
+            for (int i = 0; i < NX; ++i) { dxi[q][i] = cdx[q][i]; dxo[q][i] = 0.0; }
         for (int s = 0; s <= kend; ++s) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) dxi[q][i] = lane_below<ONE>(dxo[q][i], cdx[q][i]);
+                for (int i = 0; i < NX; ++i) dxi[q][i] = lane_below_keep<ONE>(dxi[q][i], dxo[q][i]);
                 if (kj < N) {
                     double du[NU];
                     F_rec(C, ld.ab, ld.kg, ld.kv[q], ld.rb, dxi[q], du, dxo[q]);
@@ -2145,11 +2172,12 @@ __device__ __attribute__((noinline)) double coop_F(COOP_PARAMS, const mpcx_opts 
 #pragma unroll
         for (int q = 0; q < NS; ++q) alpha[q] = dmin(alpha[q], wave_min(a.alpha[q]));      // (1 in lanes without a stage)
         if (NS == 1) {      // chains from the block's first stage up to stage kend
-            const double st1 = s1, st2 = s2;
+            // (lanes without a stage add +0; no partial sum is ever -0, so that changes nothing)
+            double i1 = s1, i2 = s2;
             for (int s = 0; s <= kend; ++s) {
-                const double i1 = lane_below<ONE>(s1, st1), i2 = lane_below<ONE>(s2, st2);
-                s1 = (j <= kend) ? i1 + a.s1 : i1;
-                s2 = (j <= kend) ? i2 + a.s2 : i2;
+                i1 = lane_below_keep<ONE>(i1, s1); i2 = lane_below_keep<ONE>(i2, s2);
+                s1 = i1 + a.s1;
+                s2 = i2 + a.s2;
             }
             s1 = bcast(s1, kend); s2 = bcast(s2, kend);
         }
@@ -2349,7 +2377,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             if (on) stage_Bs_compute<NH, ANY, true>(S, o, pc, sigma_mu, bin, t2, kr);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { o1[i] = 0.0; o2[i] = 0.0; }
-            if (kj == N) stage_Bs_rec<LAST>(S, t2, o1, o2, kvo);
+            if (kj == N) stage_Bs_rec<LAST>(S, t2, o1, o2, o1, o2, kvo);
             fresh_ab(t2.ab);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { t2.prb[i] = fresh(t2.prb[i]); t2.k0[i] = fresh(t2.k0[i]); t2.k1[i] = fresh(t2.k1[i]); }
@@ -2363,11 +2391,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
                     i1[i] = lane_above<true>(o1[i], 0.0);
                     i2[i] = lane_above<true>(o2[i], 0.0);
                 }
-                if (kj < N) {
-                    stage_Bs_rec<MID, false>(S, t2, i1, i2, kvo);
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) { o1[i] = i1[i]; o2[i] = i2[i]; }
-                }
+                if (kj < N) stage_Bs_rec<MID, false>(S, t2, i1, i2, o1, o2, kvo);
             }
             if (kj < N) {
                 feed_forward(t2.l10, t2.d0, t2.d1, kvo[0][0], kvo[0][1], kvo[0]);
