@@ -107,3 +107,22 @@ def obstacle_problems(B, duration, seed=5):
         e.verbose = False
         egos.append(e)
     return egos, sim
+
+
+def infeasible_start_problems():
+    """Start poses the constraints exclude: inside an inflated obstacle, on its margin, and outside the
+    corridor.  The rows are imposed from stage 1 on (x0 is fixed), so the first linearised QP is
+    infeasible and the solve ends with status 4; the reference holds no fixture for such a start."""
+    from mpc_amd.core_solver import EgoConfig, SimConfig
+    out = []
+    for start, obstacles in (([0, 0, 0, 1, 0], [[0.5, 0.3, 1.0, 0.5]]),
+                             ([0, 0, 0, 1, 0], [[1.2, 0.0, 1.0, 0.5]]),
+                             ([0, 9, 0, 1, 0], None)):
+        e, s = EgoConfig(), SimConfig()
+        s.duration = 10.0
+        e.state_start = start
+        e.state_final = [15, 0, 0, 0, 0]
+        e.obstacles = obstacles
+        e.verbose = False
+        out.append((e, s))
+    return out

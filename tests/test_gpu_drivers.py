@@ -263,3 +263,17 @@ def test_rti_failed_vehicle_keeps_its_plan(oracle):
     assert srv.reset() == 1 and not srv.failed.any()
     g = srv.xguess[:, :, 3].cpu().numpy()
     assert np.array_equal(g[0, :3], srv.pdata[0:3, 3].cpu().numpy()) and g[0, 3] == 1.0 and (srv.uguess[:, :, 3] == 0).all()
+
+
+def test_start_inside_constraints_matches_oracle(oracle):
+    """Start poses that the obstacle or corridor rows exclude: the device ends them exactly as the oracle
+    does (status 4 after one QP, same iteration counts), and find_path returns None."""
+    pairs = cases.infeasible_start_problems()
+    egos, sims = [p[0] for p in pairs], [p[1] for p in pairs]
+    got = solve_groups(egos, sims)
+    want = solve_groups(egos, sims, solver=oracle.solve_packed)
+    for a, b in zip(got[:3], want[:3]):
+        assert np.array_equal(a, b)
+    assert list(got[0]) == [4, 4, 4]
+    for ego, sim in pairs:
+        assert find_path(ego, sim) is None

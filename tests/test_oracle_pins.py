@@ -105,3 +105,17 @@ def test_path_finder_clears_obstacles(oracle):
         d = np.hypot(x[1:-1, 0] - ox, x[1:-1, 1] - oy)
         assert d.min() >= rad + margin - 1e-3
     assert x[:, 3].min() >= -1e-3 and x[:, 3].max() < 3.0
+
+
+def test_start_inside_constraints_fails_like_an_infeasible_qp(oracle):
+    """Behaviour pinned without a reference fixture: a start pose inside an inflated obstacle, on its
+    margin or outside the corridor is not refused at stage 0 (which carries the input rows only); the
+    rows of stage 1 cannot be met one step later, the first QP is infeasible, and the caller gets the
+    reference's failure contract: status 4, `None` from find_path."""
+    from mpc_amd.core_solver import find_path
+    pairs = cases.infeasible_start_problems()
+    st, sqp, qp, res = solve_groups([p[0] for p in pairs], [p[1] for p in pairs], solver=oracle.solve_packed)
+    assert list(st) == [4, 4, 4] and list(sqp) == [1, 1, 1]
+    assert all(15 <= q <= 50 for q in qp)
+    for ego, sim in pairs:
+        assert find_path(ego, sim, solver=oracle.solve_packed) is None
