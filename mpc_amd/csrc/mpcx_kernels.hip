@@ -3015,10 +3015,19 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         }
 
         // ---- one interior-point iteration ---------------------------------------------------
+        // The sweeps run with ALL lanes of the wavefront once any lane iterates: a store of 64 lanes
+        // covers whole 128-byte lines, while one with a few lanes switched off leaves lines covered in
+        // part, and those cost the memory system a read-modify-write each (with 2 to 3 lanes of 64
+        // sitting out, as is usual here, sweep B0 took half as long again).  A lane that sits out
+        // (waiting for service, or its problem moved to a region of its own) runs the same instructions
+        // on its own column of the workspace with no step pending: that rewrites its iterate and its
+        // multipliers unchanged -- what sweep L and the write-out read later -- and leaves unspecified
+        // values in fields that are dead until the next QP's first sweep writes them again.
         [[maybe_unused]] const bool st_c = (state == LS_QP) && !solo;
+        const bool act = (state == LS_QP) && !solo;
         bool iterate = false;
-        if (state == LS_QP && !solo) {
-            sweep_B0<NH>(L, pc, op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, m_total, ret);
+        if (__any(act)) sweep_B0<NH>(L, pc, op, act && sp.have, sp.mode, sp.sigma_mu, sp.alpha, m_total, ret);
+        if (act) {
             const double Rg = ret[0 * 64], Rb = ret[1 * 64], Rd = ret[2 * 64], Rm = ret[3 * 64];
             int qs = -1;     // HPIPM-style: 0 solved, 1 iteration limit, 3 NaN
             if (!(finite_d(Rg) && finite_d(Rb) && finite_d(Rd) && finite_d(Rm))) qs = 3;
@@ -3035,7 +3044,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         }
         STAMP(2, st_c);
         double a_aff = 0.0, sigma_mu = 0.0;
-        if (iterate) {
+        const bool any_it = __any(iterate);
+        if (any_it) {
             const double mu = ret[4 * 64];
             a_aff = sweep_F<NH, 1>(L, pc, op, 0.0, ret);
             const double S1 = ret[0 * 64], S2 = ret[1 * 64];
@@ -3047,11 +3057,13 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             sigma_mu = sigma * mu;
         }
         STAMP(3, iterate);
-        if (iterate) sweep_Bs<NH>(L, pc, op, sigma_mu);
+        if (any_it) sweep_Bs<NH>(L, pc, op, sigma_mu);
         STAMP(4, iterate);
+        double alpha1_all = 0.0;
+        if (any_it) alpha1_all = sweep_F<NH, 2>(L, pc, op, sigma_mu, ret);
         if (iterate) {
             // the corrector step, or the centring-only one where the corrector is the shorter
-            const double alpha1 = sweep_F<NH, 2>(L, pc, op, sigma_mu, ret);
+            const double alpha1 = alpha1_all;
             const double alpha2 = ret[0 * 64];
             const bool use2 = o.cond_pred_corr && (alpha1 < a_aff);
             const double alpha = use2 ? alpha2 : alpha1;
