@@ -462,12 +462,14 @@ int mpcx_ctx_solve(mpcx_ctx *c, const mpcx_batch *in, const mpcx_opts *opts, mpc
     if (!in->xguess && nh > 0)
         return fail(MPCX_E_BADARG, "xguess is NULL but the batch has obstacles: their guess (core_solver.py:360-473) is the caller's");
 
+    const char *stage_env = std::getenv("MPCX_CTX_STAGE");
+    const bool staged = stage_env && std::atoi(stage_env) != 0;
     const size_t n_pd = (size_t)MPCX_NFIELDS * B, n_xg = in->xguess ? (N + 1) * MPCX_NX * B : 0;
     const size_t n_X = B * (N + 1) * MPCX_NX, n_U = B * N * MPCX_NU;
     // buffers: kept from the last call where large enough (at least one byte each, so B = 0 yields valid pointers)
     struct { Grow *g; size_t bytes; } need[] = {
         {&c->pd, n_pd * 8}, {&c->no, B * 4}, {&c->xg, n_xg * 8}, {&c->ug, in->uguess ? n_U * 8 : 0},
-        {&c->X, n_X * 8}, {&c->U, n_U * 8}, {&c->st, B * 4}, {&c->si, B * 4}, {&c->qi, B * 4}, {&c->co, B * 8},
+        {&c->X, staged ? n_X * 8 : 0}, {&c->U, staged ? n_U * 8 : 0}, {&c->st, B * 4}, {&c->si, B * 4}, {&c->qi, B * 4}, {&c->co, B * 8},
         {&c->re, 4 * B * 8}, {&c->stats, MPCX_NSTATS * 8},
         {&c->hX, n_X * 8}, {&c->hU, n_U * 8}, {&c->hst, B * 4}, {&c->hsi, B * 4}, {&c->hqi, B * 4}, {&c->hco, B * 8},
         {&c->hre, 4 * B * 8}, {&c->hstats, MPCX_NSTATS * 8}};
@@ -511,9 +513,13 @@ int mpcx_ctx_solve(mpcx_ctx *c, const mpcx_batch *in, const mpcx_opts *opts, mpc
     din.n_obs = c->no.as<int32_t>();
     din.xguess = in->xguess ? c->xg.as<double>() : nullptr;
     din.uguess = in->uguess ? c->ug.as<double>() : nullptr;
+    // X and U, the bulk of the results, are written by the kernel straight into the handle's page-locked
+    // host arrays as each problem ends (page-locked memory is addressable from the device), so their
+    // transfer runs under the solve instead of behind it; MPCX_CTX_STAGE=1 keeps them in device memory
+    // and copies afterwards.  The small per-problem arrays stay on the device (the counters are reduced there).
     mpcx_result dout;
-    dout.X = c->X.as<double>();
-    dout.U = c->U.as<double>();
+    dout.X = staged ? c->X.as<double>() : out->X;
+    dout.U = staged ? c->U.as<double>() : out->U;
     dout.status = c->st.as<int32_t>();
     dout.sqp_iter = c->si.as<int32_t>();
     dout.qp_iter = c->qi.as<int32_t>();
@@ -522,8 +528,10 @@ int mpcx_ctx_solve(mpcx_ctx *c, const mpcx_batch *in, const mpcx_opts *opts, mpc
     HIP_TRY(mpcx_launch_sqp(nh, din, o, dout, c->ws.as<double>(), waves_to_launch(plan), plan.lanes, plan.coop_max,
                             plan.lin_max, plan.coop_layout, kSlots, q));
     HIP_TRY(mpcx_launch_stats(dout.status, dout.sqp_iter, dout.qp_iter, in->B, c->stats.as<long long>(), q));
-    HIP_TRY(hipMemcpyAsync(out->X, dout.X, n_X * 8, hipMemcpyDeviceToHost, q));
-    HIP_TRY(hipMemcpyAsync(out->U, dout.U, n_U * 8, hipMemcpyDeviceToHost, q));
+    if (staged) {
+        HIP_TRY(hipMemcpyAsync(out->X, dout.X, n_X * 8, hipMemcpyDeviceToHost, q));
+        HIP_TRY(hipMemcpyAsync(out->U, dout.U, n_U * 8, hipMemcpyDeviceToHost, q));
+    }
     HIP_TRY(hipMemcpyAsync(out->status, dout.status, B * 4, hipMemcpyDeviceToHost, q));
     HIP_TRY(hipMemcpyAsync(out->sqp_iter, dout.sqp_iter, B * 4, hipMemcpyDeviceToHost, q));
     HIP_TRY(hipMemcpyAsync(out->qp_iter, dout.qp_iter, B * 4, hipMemcpyDeviceToHost, q));

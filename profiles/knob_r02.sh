@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box sweep of the ageing knobs on the headline batch (round-2 kernel).
+# Same-box sweep of the ageing knobs on the headline batch.
 set -u
 mkdir -p gpurun_out/knob
 run() {
