@@ -92,7 +92,7 @@ def launch_ranks(args):
 
 def make_batch(args, seed, B):
     from mpc_amd.synthetic import reachable_batch, synthetic_batch
-    dev_guess = not args.host_guess
+    dev_guess = False if args.host_guess else "all"
     if args.reachable:
         return reachable_batch(B, seed=seed, device_guess=dev_guess)
     return synthetic_batch(B, seed=seed, obstacle=args.obstacle, device_guess=dev_guess)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 104
+#define MPCX_VERSION 105
 
 #define MPCX_NX 5       /* state  [x, y, theta, v, delta]        (core_solver.py:131) */
 #define MPCX_NU 2       /* input  [acceleration, steering rate]  (core_solver.py:132) */
@@ -67,10 +67,10 @@ typedef struct mpcx_batch {
     const double  *pdata;   /* [MPCX_NFIELDS][B]                                      */
     const int32_t *n_obs;   /* [B], each 0..MPCX_MAX_OBS                              */
     const double  *xguess;  /* [N+1][5][B] initial state guess (core_solver.py:477-499), or NULL: the
-                               library computes it on the device from the table, for problems
-                               without obstacles only (the obstacle branch :360-473 is the caller's:
-                               a problem with n_obs > 0 and no guess ends with status MPCX_NAN and
-                               zero iterations; the host entry points refuse such a batch)          */
+                               library computes it on the device from the table (see
+                               mpcx_initial_guess: identical to the host loop without obstacles;
+                               with obstacles the reference's formulas :360-473 with products for
+                               its pow(x, 2) and a unit vector for its cos / sin of arctan2)      */
     const double  *uguess;  /* [N][2][B] initial input guess, or NULL = zeros, which is what the
                                reference starts from (it never sets "u"); used by receding-
                                horizon callers that shift the previous solution              */
@@ -160,19 +160,24 @@ int    mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts,
 int mpcx_solve_batch_static(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *out, void *stream);
 
 /*
- * Initial state guess of core_solver.py:477-499 for problems WITHOUT obstacles (its obstacle
- * branch, adjust_point_for_obstacles :360-473, stays on the host), computed on the device from
- * the problem table: node i gets the start-goal interpolation at t = i/N, y clamped to the
- * reference's centre-line formula +- width/2, heading interpolated, v = 1 - t, delta = 0;
- * node N gets the goal state.  Same operations in the same order as the host loop, so the
- * result is bit-identical to it.  width[b] = EgoConfig.corridor_width (core_solver.py:27), or
- * width == NULL: the table's own MPCX_F_CW column.
- * _device: pdata [MPCX_NFIELDS][B], width [B], xguess [N+1][5][B] are device pointers and the
- * kernel is queued on `stream`; the other form takes host pointers and device `device`.
+ * Initial state guess of core_solver.py:477-499, computed on the device from the problem table:
+ * node i gets the start-goal interpolation at t = i/N, y clamped to the reference's centre-line
+ * formula +- width/2, heading interpolated, v = 1 - t, delta = 0; node N gets the goal state.
+ * Without obstacles (n_obs == NULL, or n_obs[b] == 0) these are the same operations in the same
+ * order as the host loop and the result is bit-identical to it.  With obstacles every point is then
+ * moved off them as adjust_point_for_obstacles does (:360-473: the start-goal line shifted sideways
+ * past an obstacle that straddles it and the point projected on it, else a point inside an obstacle
+ * pushed out radially to radius + margin + 0.05), with two differences in the last bits: squares
+ * are products where the reference calls pow(x, 2), and the radial direction is (dx, dy) / distance
+ * where the reference takes cos and sin of arctan2(dy, dx) from the host libm.
+ * width[b] = EgoConfig.corridor_width (core_solver.py:27), or width == NULL: the table's own
+ * MPCX_F_CW column.
+ * _device: pdata [MPCX_NFIELDS][B], n_obs [B], width [B], xguess [N+1][5][B] are device pointers and
+ * the kernel is queued on `stream`; the other form takes host pointers and device `device`.
  */
-int mpcx_initial_guess_device(const double *pdata, const double *width, int32_t B, int32_t N,
+int mpcx_initial_guess_device(const double *pdata, const int32_t *n_obs, const double *width, int32_t B, int32_t N,
                               double *xguess, void *stream);
-int mpcx_initial_guess(const double *pdata, const double *width, int32_t B, int32_t N,
+int mpcx_initial_guess(const double *pdata, const int32_t *n_obs, const double *width, int32_t B, int32_t N,
                        double *xguess, int device);
 
 enum { MPCX_STAT_SQP = 5, MPCX_STAT_QP = 6, MPCX_STAT_LIN = 7, MPCX_NSTATS = 8 };

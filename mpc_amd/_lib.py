@@ -77,9 +77,9 @@ def load_library(path=None):
                                             C.POINTER(MpcxResult), C.c_void_p,
                                             C.c_size_t, C.c_void_p]
     lib.mpcx_solve_batch_device.restype = C.c_int
-    lib.mpcx_initial_guess_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.mpcx_initial_guess_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.mpcx_initial_guess_device.restype = C.c_int
-    lib.mpcx_initial_guess.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int]
+    lib.mpcx_initial_guess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int]
     lib.mpcx_initial_guess.restype = C.c_int
     lib.mpcx_batch_stats_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.mpcx_batch_stats_device.restype = C.c_int
@@ -215,19 +215,22 @@ class Context:
             pass
 
 
-def initial_guess_on_device(pdata, width, N, device=0):
-    """xguess [N+1, 5, B] of obstacle-free problems computed on HIP device ``device`` from the
-    problem table (host arrays in, host array out); bit-identical to batch.initial_guess_batch.
-    width None = the table's own corridor-width column."""
+def initial_guess_on_device(pdata, width, N, device=0, n_obs=None):
+    """xguess [N+1, 5, B] computed on HIP device ``device`` from the problem table (host arrays in,
+    host array out); bit-identical to batch.library_guess, and without obstacles (n_obs None or
+    zeros) to batch.initial_guess_batch.  width None = the table's own corridor-width column."""
     lib = load_library()
     if lib.mpcx_device_count() <= 0:
         raise MpcxError("no HIP device available (there is no CPU fallback)")
     pdata = np.ascontiguousarray(pdata, dtype=np.float64)
     if width is not None:
         width = np.ascontiguousarray(width, dtype=np.float64)
+    if n_obs is not None:
+        n_obs = np.ascontiguousarray(n_obs, dtype=np.int32)
     B = pdata.shape[1]
     out = np.empty((N + 1, 5, B), dtype=np.float64)
-    _check(lib, lib.mpcx_initial_guess(pdata.ctypes.data, width.ctypes.data if width is not None else None,
+    _check(lib, lib.mpcx_initial_guess(pdata.ctypes.data, n_obs.ctypes.data if n_obs is not None else None,
+                                       width.ctypes.data if width is not None else None,
                                        B, N, out.ctypes.data, int(device)),
            "mpcx_initial_guess")
     return out

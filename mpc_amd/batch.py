@@ -50,14 +50,10 @@ class PackedBatch:
 
     def guess(self):
         """The state guess as a host array [N+1, 5, B]: the packed one, or, where the batch leaves
-        it to the device, the host loop on the same table (identical to the device's, bit for bit)."""
+        it to the device, the same operations on the host (identical to the device's, bit for bit)."""
         if self.xguess is not None:
             return self.xguess
-        if self.B and int(self.n_obs.max()) > 0:
-            raise ValueError("a batch with obstacles carries its guess (core_solver.py:360-473 runs on the host)")
-        pd = self.pdata
-        return initial_guess_batch(pd[F_X0:F_X0 + 5].T, pd[F_GOAL:F_GOAL + 5].T, pd[F_CW], self.N,
-                                   pd[F_CG + 2], pd[F_UG], -pd[F_UG + 1])
+        return library_guess(self.pdata, self.n_obs, self.N)
 
     def take(self, idx):
         """The problems ``idx`` (an index array or a slice) as a batch of their own."""
@@ -210,6 +206,83 @@ def adjust_points_one_obstacle(start, goal, x, y, obstacle):
     return np.where(degenerate, x, x_out), np.where(degenerate, y, y_out)
 
 
+def library_guess(pdata, n_obs, N):
+    """The guess the library computes from the problem table when none is handed over
+    (mpcx_batch.xguess NULL), restated operation for operation in numpy: [N+1, 5, B].
+
+    Without obstacles it IS the reference's loop (core_solver.py:477-499).  With obstacles every
+    point is moved off them by the reference's rules (:360-473) for up to four obstacles per
+    problem, with products where the reference squares by pow(x, 2) and the unit vector
+    (dx, dy) / distance where it takes cos and sin of arctan2(dy, dx): the same formulas, a
+    last-bit difference in those two places, no dependence on the host's libm.
+    """
+    pd = pdata
+    B = pd.shape[1]
+    sx, sy, gx, gy = pd[F_X0], pd[F_X0 + 1], pd[F_GOAL], pd[F_GOAL + 1]
+    a, b1, b2, half = pd[F_CG + 2], pd[F_UG], -pd[F_UG + 1], pd[F_CW] / 2
+    nob = np.zeros(B, dtype=np.int64) if n_obs is None else np.asarray(n_obs, dtype=np.int64)
+    maxo = int(nob.max()) if B else 0
+    out = np.empty((N + 1, NX, B), dtype=np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        pdx = gx - sx
+        pdy = gy - sy
+        plen = np.sqrt(pdx * pdx + pdy * pdy)
+        skip = plen < 1e-6
+        pdx = pdx / plen
+        pdy = pdy / plen
+        ndx, ndy = -pdy, pdx
+        tr = [np.sqrt(pd[F_OBS + 3 * j + 2]) + 0.05 for j in range(maxo)]
+        for i in range(N):
+            t = float(i) / N
+            x = sx + t * (gx - sx)
+            y = sy + t * (gy - sy)
+            yc = -(((a * x + b1 / 2) + a * x) + b2 / 2) / 2
+            lo, hi = yc - half, yc + half
+            y = np.where(y > lo, y, lo)
+            y = np.where(y < hi, y, hi)
+            if maxo:
+                shift = np.zeros(B)
+                direction = np.ones(B)
+                for j in range(maxo):
+                    ox, oy = pd[F_OBS + 3 * j], pd[F_OBS + 3 * j + 1]
+                    projection = (ox - sx) * pdx + (oy - sy) * pdy
+                    ex = (sx + projection * pdx) - ox
+                    ey = (sy + projection * pdy) - oy
+                    dist = np.sqrt(ex * ex + ey * ey)
+                    hit = (j < nob) & ~skip & (dist < tr[j]) & (0.0 <= projection) & (projection <= plen)
+                    side = (x - sx) * ndx + (y - sy) * ndy
+                    direction = np.where(hit & (side < 0.0), -1.0, direction)
+                    needed = tr[j] - dist
+                    shift = np.where(hit & (needed > shift), needed, shift)
+                shifted = shift > 0.0
+                amount = shift + 0.1
+                ssx = sx + direction * ndx * amount
+                ssy = sy + direction * ndy * amount
+                proj = (x - ssx) * pdx + (y - ssy) * pdy
+                proj = np.where(proj < plen, proj, plen)
+                proj = np.where(proj > 0.0, proj, 0.0)
+                xs, ys = ssx + proj * pdx, ssy + proj * pdy
+                xp, yp = x, y
+                for j in range(maxo):
+                    ox, oy = pd[F_OBS + 3 * j], pd[F_OBS + 3 * j + 1]
+                    dx, dy = xp - ox, yp - oy
+                    d = np.sqrt(dx * dx + dy * dy)
+                    inside = (j < nob) & ~skip & ~shifted & (d < tr[j])
+                    ux = np.where(d > 0.0, dx / d, 1.0)
+                    uy = np.where(d > 0.0, dy / d, 0.0)
+                    xp = np.where(inside, ox + tr[j] * ux, xp)
+                    yp = np.where(inside, oy + tr[j] * uy, yp)
+                x = np.where(shifted, xs, xp)
+                y = np.where(shifted, ys, yp)
+            out[i, 0] = x
+            out[i, 1] = y
+            out[i, 2] = pd[F_X0 + 2] + t * (pd[F_GOAL + 2] - pd[F_X0 + 2])
+            out[i, 3] = 1.0 * (1 - t)
+            out[i, 4] = 0.0
+    out[N] = pd[F_GOAL:F_GOAL + 5]
+    return out
+
+
 def initial_guess_batch(start, goal, width, N, a, b1, b2, obstacle=None):
     """Vectorised ``initial_guess``.
 
@@ -292,7 +365,9 @@ def pack_problems(egos, sim_cfg, errors=None, device_guess=False):
     obstacles, a state of the wrong length ...) raises.  A dict = such egos are left out of the
     batch, ``errors[i]`` receives the exception of ego i, and the batch holds the others in
     their order (the reference isolates failures per problem, core_solver.py:540-562).
-    device_guess: leave the state guess of an obstacle-free batch to the library (xguess None).
+    device_guess: True = leave the state guess of an obstacle-free batch to the library (xguess
+    None); "all" = also that of a batch with obstacles (library_guess says what the library computes
+    there: the reference's rules, two operations spelled differently).
     """
     N = horizon_length(sim_cfg)
     if N < 1:
@@ -315,7 +390,7 @@ def pack_problems(egos, sim_cfg, errors=None, device_guess=False):
     if B:
         pdata[:, :] = np.array(cols).T
     n_obs = np.array(counts, dtype=np.int32).reshape(B)
-    if device_guess and (B == 0 or int(n_obs.max()) == 0):
+    if device_guess == "all" or (device_guess and (B == 0 or int(n_obs.max()) == 0)):
         return PackedBatch(B, N, pdata, n_obs, None, float(sim_cfg.duration))
     xguess = np.empty((N + 1, NX, B), dtype=np.float64)
     for b, i in enumerate(kept):
@@ -342,7 +417,8 @@ def pack_arrays(start, goal, duration, dt=0.1, corridor_width=15.0, L=2.7,
     """Vectorised packing of problems that differ only in start and goal state
     (the synthetic benchmark batch, the grid sweep) and, optionally, in the one
     obstacle each has (obstacle: [B, 4] rows x, y, radius, margin).
-    device_guess: leave the state guess of an obstacle-free batch to the library (xguess None).
+    device_guess: True = leave the state guess of an obstacle-free batch to the library (xguess
+    None); "all" = also that of a batch with obstacles (see library_guess).
 
     start, goal: [B, 5]; headings are wrapped exactly as the EgoConfig setters
     wrap them.  Every other EgoConfig field takes the given common value
@@ -389,7 +465,7 @@ def pack_arrays(start, goal, duration, dt=0.1, corridor_width=15.0, L=2.7,
         pdata[F_OBS + 1] = obstacle[:, 1]
         pdata[F_OBS + 2] = (obstacle[:, 2] + obstacle[:, 3])**2
         n_obs[:] = 1
-    if device_guess and obstacle is None:
+    if device_guess == "all" or (device_guess and obstacle is None):
         return PackedBatch(B, N, pdata, n_obs, None, float(duration))
     xguess = initial_guess_batch(start, goal, width, N, a, b1, b2, obstacle)
     return PackedBatch(B, N, pdata, n_obs, xguess, float(duration))

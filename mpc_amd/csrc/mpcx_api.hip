@@ -289,8 +289,6 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     }
     if (o.max_obs >= 0 && o.max_obs < nh) return fail(MPCX_E_BADARG, "max_obs %d < largest n_obs %d", o.max_obs, nh);
     o.max_obs = nh;
-    if (!in->xguess && nh > 0)
-        return fail(MPCX_E_BADARG, "xguess is NULL but the batch has obstacles: their guess (core_solver.py:360-473) is the caller's");
 
     const size_t n_pd = (size_t)MPCX_NFIELDS * B, n_xg = in->xguess ? (N + 1) * MPCX_NX * B : 0;
     const size_t n_X = B * (N + 1) * MPCX_NX, n_U = B * N * MPCX_NU;
@@ -354,18 +352,18 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     return 0;
 }
 
-int mpcx_initial_guess_device(const double *pdata, const double *width, int32_t B, int32_t N,
+int mpcx_initial_guess_device(const double *pdata, const int32_t *n_obs, const double *width, int32_t B, int32_t N,
                               double *xguess, void *stream)
 {
     if (B < 0 || N < 1) return fail(MPCX_E_BADARG, "need B >= 0 and N >= 1 (B=%d, N=%d)", B, N);
     if (B == 0) return 0;
     if (!pdata || !xguess) return fail(MPCX_E_BADARG, "null argument");
     if (mpcx_device_count() <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
-    HIP_TRY(mpcx_launch_guess(pdata, width, B, N, xguess, static_cast<hipStream_t>(stream)));
+    HIP_TRY(mpcx_launch_guess(pdata, n_obs, width, B, N, xguess, static_cast<hipStream_t>(stream)));
     return 0;
 }
 
-int mpcx_initial_guess(const double *pdata, const double *width, int32_t B, int32_t N,
+int mpcx_initial_guess(const double *pdata, const int32_t *n_obs, const double *width, int32_t B, int32_t N,
                        double *xguess, int device)
 {
     if (B < 0 || N < 1) return fail(MPCX_E_BADARG, "need B >= 0 and N >= 1 (B=%d, N=%d)", B, N);
@@ -376,15 +374,22 @@ int mpcx_initial_guess(const double *pdata, const double *width, int32_t B, int3
     if (device < 0 || device >= ndev) return fail(MPCX_E_BADARG, "device %d out of range [0, %d)", device, ndev);
     HIP_TRY(hipSetDevice(device));
     const size_t n_pd = (size_t)MPCX_NFIELDS * B, n_xg = (size_t)(N + 1) * MPCX_NX * B;
-    DevBuf d_pd, d_w, d_xg;
+    if (n_obs) {
+        for (int32_t b = 0; b < B; ++b)
+            if (n_obs[b] < 0 || n_obs[b] > MPCX_MAX_OBS)
+                return fail(MPCX_E_BADARG, "n_obs[%d] = %d outside [0, %d]", b, n_obs[b], MPCX_MAX_OBS);
+    }
+    DevBuf d_pd, d_w, d_no, d_xg;
     if (d_pd.alloc(n_pd * 8) != hipSuccess || d_w.alloc((size_t)B * 8) != hipSuccess ||
-        d_xg.alloc(n_xg * 8) != hipSuccess) {
+        d_no.alloc((size_t)B * 4) != hipSuccess || d_xg.alloc(n_xg * 8) != hipSuccess) {
         (void)hipGetLastError();
         return fail(MPCX_E_NOMEM, "device allocation failed");
     }
     HIP_TRY(hipMemcpy(d_pd.p, pdata, n_pd * 8, hipMemcpyHostToDevice));
     if (width) HIP_TRY(hipMemcpy(d_w.p, width, (size_t)B * 8, hipMemcpyHostToDevice));
-    HIP_TRY(mpcx_launch_guess(d_pd.as<double>(), width ? d_w.as<double>() : nullptr, B, N, d_xg.as<double>(), nullptr));
+    if (n_obs) HIP_TRY(hipMemcpy(d_no.p, n_obs, (size_t)B * 4, hipMemcpyHostToDevice));
+    HIP_TRY(mpcx_launch_guess(d_pd.as<double>(), n_obs ? d_no.as<int32_t>() : nullptr, width ? d_w.as<double>() : nullptr,
+                              B, N, d_xg.as<double>(), nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(xguess, d_xg.p, n_xg * 8, hipMemcpyDeviceToHost));
     return 0;
@@ -459,8 +464,6 @@ int mpcx_ctx_solve(mpcx_ctx *c, const mpcx_batch *in, const mpcx_opts *opts, mpc
     }
     if (o.max_obs >= 0 && o.max_obs < nh) return fail(MPCX_E_BADARG, "max_obs %d < largest n_obs %d", o.max_obs, nh);
     o.max_obs = nh;
-    if (!in->xguess && nh > 0)
-        return fail(MPCX_E_BADARG, "xguess is NULL but the batch has obstacles: their guess (core_solver.py:360-473) is the caller's");
 
     const char *stage_env = std::getenv("MPCX_CTX_STAGE");
     const bool staged = stage_env && std::atoi(stage_env) != 0;

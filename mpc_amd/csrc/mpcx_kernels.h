@@ -25,7 +25,8 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
                            double *workspace, int n_waves, int lanes, int coop_max, int lin_max, int coop_layout, int slots, hipStream_t stream);
 
 // initial guess of obstacle-free problems from the problem table (device pointers)
-hipError_t mpcx_launch_guess(const double *pdata, const double *width, int B, int N, double *xguess, hipStream_t stream);
+hipError_t mpcx_launch_guess(const double *pdata, const int32_t *n_obs, const double *width, int B, int N, double *xguess,
+                             hipStream_t stream);
 
 // outcome counters of a solved batch (device pointers; stats = 8 x int64, zeroed by the launcher)
 hipError_t mpcx_launch_stats(const int32_t *status, const int32_t *sqp_iter, const int32_t *qp_iter, int B,

@@ -425,10 +425,11 @@ DEV void mul_AB(const Lane &L, const AB &ab, const double *dx, const double *du,
 // +- width/2, heading interpolated, v = 1 - t, delta = 0; node N is the goal state.  The same
 // operations in the same order as the reference's loop, so a host program gets the same bits.
 // ---------------------------------------------------------------------------
-struct GuessData { double s[NX], g[NX], a, b1, b2, half; };
+struct GuessData { double s[NX], g[NX], a, b1, b2, half; int nobs; double ox[MPCX_MAX_OBS], oy[MPCX_MAX_OBS], tr[MPCX_MAX_OBS]; };
 
-// problem b's column of the table; width = the caller's column, or NULL = the table's own
-DEV void guess_data(const double *pdata, const double *width, size_t Bs, size_t b, GuessData &G)
+// problem b's column of the table; width = the caller's column, or NULL = the table's own;
+// nobs = the problem's obstacle count (0: the obstacle columns are not read)
+DEV void guess_data(const double *pdata, const double *width, size_t Bs, size_t b, int nobs, GuessData &G)
 {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -440,6 +441,75 @@ DEV void guess_data(const double *pdata, const double *width, size_t Bs, size_t 
     G.b1 = pdata[(size_t)(MPCX_F_UG + 0) * Bs + b];
     G.b2 = -pdata[(size_t)(MPCX_F_UG + 1) * Bs + b];
     G.half = (width ? width[b] : pdata[(size_t)MPCX_F_CW * Bs + b]) / 2;
+    G.nobs = nobs;
+#pragma unroll
+    for (int j = 0; j < MPCX_MAX_OBS; ++j) {
+        G.ox[j] = G.oy[j] = 0.0;
+        G.tr[j] = -1.0;
+        if (j < nobs) {
+            G.ox[j] = pdata[(size_t)(MPCX_F_OBS + 3 * j) * Bs + b];
+            G.oy[j] = pdata[(size_t)(MPCX_F_OBS + 3 * j + 1) * Bs + b];
+            // the table holds (r + margin)^2 as the product of the rounded sum with itself, whose
+            // correctly rounded root is that sum again; the guess keeps 0.05 m more (core_solver.py:393)
+            G.tr[j] = sqrt(pdata[(size_t)(MPCX_F_OBS + 3 * j + 2) * Bs + b]) + 0.05;
+        }
+    }
+}
+
+// A guess point moved off the obstacles (reference core_solver.py:360-473): if an obstacle straddles
+// the start-goal line the whole line is shifted sideways by the largest intrusion + 0.1 m (to the side
+// of the point; the side sticks once negative) and the point projected onto the shifted segment;
+// otherwise a point inside an obstacle is pushed out radially to its inflated radius, obstacle after
+// obstacle.  Two places are not the reference's arithmetic to the last bit: its squares are pow(x, 2)
+// where these are products, and its radial direction is (cos, sin) of arctan2(dy, dx) where this is
+// (dx, dy) / hypotenuse (the same unit vector, free of the host's libm).
+DEV void guess_adjust(const GuessData &G, double &x, double &y)
+{
+    if (G.nobs <= 0) return;
+    const double sx = G.s[0], sy = G.s[1];
+    double pdx = G.g[0] - sx, pdy = G.g[1] - sy;
+    const double plen = sqrt(pdx * pdx + pdy * pdy);
+    if (plen < 1e-6) return;
+    pdx = pdx / plen;
+    pdy = pdy / plen;
+    const double ndx = -pdy, ndy = pdx;
+    double path_shift = 0.0, dir = 1.0;
+#pragma unroll
+    for (int j = 0; j < MPCX_MAX_OBS; ++j) {
+        if (j >= G.nobs) continue;
+        const double odx = G.ox[j] - sx, ody = G.oy[j] - sy;
+        const double projection = odx * pdx + ody * pdy;
+        const double cx = sx + projection * pdx, cy = sy + projection * pdy;
+        const double ex = cx - G.ox[j], ey = cy - G.oy[j];
+        const double dist = sqrt(ex * ex + ey * ey);
+        if (dist < G.tr[j] && 0.0 <= projection && projection <= plen) {
+            const double side = (x - sx) * ndx + (y - sy) * ndy;
+            if (side < 0.0) dir = -1.0;
+            const double needed = G.tr[j] - dist;
+            if (needed > path_shift) path_shift = needed;
+        }
+    }
+    if (path_shift > 0.0) {
+        const double amount = path_shift + 0.1;
+        const double ssx = sx + dir * ndx * amount, ssy = sy + dir * ndy * amount;
+        double proj = (x - ssx) * pdx + (y - ssy) * pdy;
+        proj = (proj < plen) ? proj : plen;
+        proj = (proj > 0.0) ? proj : 0.0;
+        x = ssx + proj * pdx;
+        y = ssy + proj * pdy;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < MPCX_MAX_OBS; ++j) {
+        if (j >= G.nobs) continue;
+        const double dx = x - G.ox[j], dy = y - G.oy[j];
+        const double d = sqrt(dx * dx + dy * dy);
+        if (d < G.tr[j]) {
+            const double ux = (d > 0.0) ? dx / d : 1.0, uy = (d > 0.0) ? dy / d : 0.0;
+            x = G.ox[j] + G.tr[j] * ux;
+            y = G.oy[j] + G.tr[j] * uy;
+        }
+    }
 }
 
 DEV void guess_node(const GuessData &G, int i, int N, double *o)
@@ -450,12 +520,13 @@ DEV void guess_node(const GuessData &G, int i, int N, double *o)
         return;
     }
     const double t = (double)i / (double)N;
-    const double x = G.s[0] + t * (G.g[0] - G.s[0]);
+    double x = G.s[0] + t * (G.g[0] - G.s[0]);
     double y = G.s[1] + t * (G.g[1] - G.s[1]);
     const double yc = -(((G.a * x + G.b1 / 2) + G.a * x) + G.b2 / 2) / 2;
     const double lo = yc - G.half, hi = yc + G.half;
     y = (y > lo) ? y : lo;
     y = (y < hi) ? y : hi;
+    guess_adjust(G, x, y);
     o[0] = x;
     o[1] = y;
     o[2] = G.s[2] + t * (G.g[2] - G.s[2]);
@@ -2896,9 +2967,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                     L.b = b;
                     L.roff = 0;
                     int nobs = in.n_obs ? in.n_obs[b] : 0;
-                    // (the host validates both; stay memory safe, and never solve an obstacle problem from
-                    // the obstacle-free guess: the reference moves its guess off the obstacles, :360-473)
-                    if (nobs < 0 || nobs > NH || (nobs > 0 && !in.xguess)) {
+                    // (the host validates it; stay memory safe)
+                    if (nobs < 0 || nobs > NH) {
                         out.status[b] = MPCX_NAN;
                         out.sqp_iter[b] = 0;
                         out.qp_iter[b] = 0;
@@ -2933,7 +3003,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                 Lane C;
                 problem_home(L, p, C);
                 GuessData G;
-                if (!in.xguess) guess_data(in.pdata, nullptr, L.B, b, G);      // no guess handed over: computed here
+                if (!in.xguess)      // no guess handed over: computed here
+                    guess_data(in.pdata, nullptr, L.B, b, __builtin_amdgcn_readlane(L.nobs, p), G);
                 for (int k0 = 0; k0 <= N; k0 += 64) {
                     const int kj = k0 + (int)threadIdx.x;
                     if (kj > N) continue;
@@ -3154,13 +3225,16 @@ __global__ void mpcx_header_kernel(int *counter, mpcx_opts *d_opts, mpcx_opts o)
 
 // initial guess without obstacles (reference core_solver.py:477-499): one thread per problem,
 // node by node; every store of a wavefront is one contiguous segment of xguess[i][c][:]
-__global__ void mpcx_guess_kernel(const double *pdata, const double *width, int B, int N, double *xguess)
+__global__ void mpcx_guess_kernel(const double *pdata, const int32_t *n_obs, const double *width, int B, int N,
+                                  double *xguess)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const size_t Bs = (size_t)B;
     GuessData G;
-    guess_data(pdata, width, Bs, (size_t)b, G);
+    int nobs = n_obs ? n_obs[b] : 0;
+    nobs = (nobs < 0) ? 0 : (nobs > MPCX_MAX_OBS) ? MPCX_MAX_OBS : nobs;
+    guess_data(pdata, width, Bs, (size_t)b, nobs, G);
     for (int i = 0; i <= N; ++i) {
         double o[NX];
         guess_node(G, i, N, o);
@@ -3300,9 +3374,10 @@ extern "C" int mpcx_debug_read_stamps(unsigned long long *out, int reset)
 }
 #endif
 
-hipError_t mpcx_launch_guess(const double *pdata, const double *width, int B, int N, double *xguess, hipStream_t stream)
+hipError_t mpcx_launch_guess(const double *pdata, const int32_t *n_obs, const double *width, int B, int N, double *xguess,
+                             hipStream_t stream)
 {
-    hipLaunchKernelGGL(mpcx_guess_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, pdata, width, B, N, xguess);
+    hipLaunchKernelGGL(mpcx_guess_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, pdata, n_obs, width, B, N, xguess);
     return hipGetLastError();
 }
 

@@ -132,12 +132,10 @@ class RtiServer:
         vehicles = t.as_tensor(vehicles, device=self.dev, dtype=t.long)
         if vehicles.numel() == 0:
             return 0
-        if int(self.n_obs.max()) > 0:
-            raise _lib.MpcxError("reset needs an obstacle-free fleet")
         fresh = t.empty_like(self.xguess)
         stream = t.cuda.current_stream()
-        rc = self.lib.mpcx_initial_guess_device(self.pdata.data_ptr(), None, self.B, self.N, fresh.data_ptr(),
-                                                stream.cuda_stream)
+        rc = self.lib.mpcx_initial_guess_device(self.pdata.data_ptr(), self.n_obs.data_ptr(), None, self.B, self.N,
+                                                fresh.data_ptr(), stream.cuda_stream)
         if rc != 0:
             raise _lib.MpcxError(self.lib.mpcx_last_error().decode())
         self.xguess[:, :, vehicles] = fresh[:, :, vehicles]

@@ -50,11 +50,11 @@ def random_start_goal(B, seed=SEED, with_obstacle=False):
 
 def synthetic_batch(B, seed=SEED, duration=5.0, dt=0.1, obstacle=False, device_guess=False):
     """PackedBatch of B random problems (N = int(duration/dt)), without obstacles
-    or with one obstacle each.  device_guess: leave the guess of the obstacle-free batch to the
-    library (xguess None)."""
+    or with one obstacle each.  device_guess: as in pack_arrays (True: the guess of an
+    obstacle-free batch is left to the library; "all": that of the obstacle batch too)."""
     if obstacle:
         start, goal, obs = random_start_goal(B, seed, with_obstacle=True)
-        return pack_arrays(start, goal, duration, dt, obstacle=obs)
+        return pack_arrays(start, goal, duration, dt, obstacle=obs, device_guess=device_guess)
     start, goal = random_start_goal(B, seed)
     return pack_arrays(start, goal, duration, dt, device_guess=device_guess)
 

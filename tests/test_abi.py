@@ -27,7 +27,7 @@ def test_exports_match_header():
             "mpcx_max_horizon"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mpcx.h but not exported"
-    assert lib.mpcx_version() == 104
+    assert lib.mpcx_version() == 105
 
 
 def test_struct_layout_and_defaults():
@@ -65,15 +65,6 @@ def test_bad_arguments_and_no_device():
     assert lib.mpcx_solve_batch(C.byref(b), C.byref(o), C.byref(r), 0) == -1
     assert b"too large" in lib.mpcx_last_error()
     b.N = p.N
-    # a batch with obstacles and no guess is refused by the host entry point (the guess of
-    # core_solver.py:360-473 is the caller's)
-    if lib.mpcx_device_count() > 0:
-        b.xguess = None
-        no = np.ones(p.B, dtype=np.int32)
-        b.n_obs = no.ctypes.data
-        assert lib.mpcx_solve_batch(C.byref(b), C.byref(o), C.byref(r), 0) == -1
-        assert b"xguess is NULL" in lib.mpcx_last_error()
-        b = _lib.batch_struct(p)
     h = C.c_void_p()
     assert lib.mpcx_ctx_create(None, 0) == -1
     lib.mpcx_ctx_destroy(None)

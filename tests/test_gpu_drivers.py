@@ -169,8 +169,8 @@ def test_config3_scenarios_with_obstacles(oracle):
 
 def test_guess_computed_by_the_library(oracle):
     """xguess NULL: the solve computes the guess of core_solver.py:477-499 itself, node per lane;
-    same results as with the host's array, bit for bit; obstacle problems without a guess are
-    refused (host entry) or end with status 1 and zero iterations (device entry)."""
+    same results as with the host's array, bit for bit; with obstacles the library's guess follows
+    the reference's rules (batch.library_guess is its restatement)."""
     import ctypes as C
     packed = synthetic_batch(3000)
     bare = type(packed)(packed.B, packed.N, packed.pdata, packed.n_obs, None, packed.duration)
@@ -192,26 +192,21 @@ def test_guess_computed_by_the_library(oracle):
     assert (st_g == st_o).all()
     for a_, b_ in zip(res_g, res_o):
         assert np.array_equal(a_["x"], b_["x"]) and np.array_equal(a_["u"], b_["u"])
-    # device entry point, obstacles but no guess
-    lib = _lib.load_library()
-    obs = synthetic_batch(64, obstacle=True)
-    dev = torch.device("cuda", 0)
-    d_pd, d_no = torch.from_numpy(obs.pdata).to(dev), torch.from_numpy(obs.n_obs).to(dev)
-    B, N = obs.B, obs.N
-    d = {"X": torch.zeros((B, N + 1, 5), dtype=torch.float64, device=dev), "U": torch.zeros((B, N, 2), dtype=torch.float64, device=dev),
-         "status": torch.full((B,), -1, dtype=torch.int32, device=dev), "sqp_iter": torch.full((B,), -1, dtype=torch.int32, device=dev),
-         "qp_iter": torch.full((B,), -1, dtype=torch.int32, device=dev), "cost": torch.zeros(B, dtype=torch.float64, device=dev),
-         "res": torch.zeros((4, B), dtype=torch.float64, device=dev)}
-    ws_bytes = lib.mpcx_workspace_bytes(B, N)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    bs = _lib.MpcxBatch(B, N, d_pd.data_ptr(), d_no.data_ptr(), None, None)
-    rs = _lib.MpcxResult(*(d[k].data_ptr() for k in ("X", "U", "status", "sqp_iter", "qp_iter", "cost", "res")))
-    o = _lib.default_opts()
-    rc = lib.mpcx_solve_batch_device(C.byref(bs), C.byref(o), C.byref(rs), ws.data_ptr(), ws_bytes,
-                                     torch.cuda.current_stream().cuda_stream)
-    assert rc == 0, lib.mpcx_last_error()
-    torch.cuda.synchronize()
-    assert (d["status"].cpu().numpy() == 1).all() and (d["sqp_iter"].cpu().numpy() == 0).all()
+    # batches with obstacles and no guess: the library moves its guess off the obstacles by the
+    # reference's rules; the numpy restatement of that (PackedBatch.guess) is the same array bit for bit,
+    # and the solve from it matches the oracle's
+    obs = synthetic_batch(2000, obstacle=True, device_guess="all")
+    assert obs.xguess is None and int(obs.n_obs.min()) == 1
+    dev_guess = _lib.initial_guess_on_device(obs.pdata, None, obs.N, n_obs=obs.n_obs)
+    assert np.array_equal(dev_guess, obs.guess())
+    assert np.abs(dev_guess - synthetic_batch(2000, obstacle=True).xguess).max() < 1e-12
+    cases.assert_same_solution(_lib.solve_packed(obs), oracle.solve_packed(obs), "library guess, one obstacle each")
+    pairs = [cases.make_scenario("path_finder")] + [(e, s) for _, e, s in _config3_cases()[:4]]
+    for ego, sim in pairs:
+        p = pack_problems([ego], sim, device_guess="all")
+        assert p.xguess is None
+        assert np.array_equal(_lib.initial_guess_on_device(p.pdata, None, p.N, n_obs=p.n_obs), p.guess())
+        cases.assert_same_solution(_lib.solve_packed(p), oracle.solve_packed(p), "library guess, scenario with obstacles")
 
 
 def test_context_reuses_its_buffers(oracle):

@@ -229,9 +229,52 @@ def test_guess_left_to_the_library_is_the_host_loop():
     ego, sim = cases.make_scenario("path_finder")
     p = bt.pack_problems([ego], sim, device_guess=True)
     assert p.xguess is not None and p.pdata[bt.F_CW, 0] == 10.0
+    q = bt.pack_problems([ego], sim, device_guess="all")
+    assert q.xguess is None and np.array_equal(q.pdata, p.pdata)
     ego, sim = cases.make_scenario("line")
     p = bt.pack_problems([ego], sim, device_guess=True)
     assert p.xguess is None and np.array_equal(p.guess()[:, :, 0], bt.initial_guess(ego, p.N))
+
+
+def test_library_guess_with_obstacles_follows_the_reference_rules():
+    """What the library computes when a batch with obstacles brings no guess (restated in numpy,
+    batch.library_guess): the reference's rules -- line shifted past a straddling obstacle, points
+    inside an obstacle pushed out radially, several obstacles, sticky side -- to within rounding of the
+    scalar routine that uses the reference's own operations (pow and arctan2 / cos / sin)."""
+    from mpc_amd.core_solver import EgoConfig, SimConfig
+    rng = np.random.default_rng(11)
+    egos = []
+    sim = SimConfig()
+    sim.duration = 6.0
+    for k in range(60):
+        e = EgoConfig()
+        e.state_start = [rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-1, 1), 0.5, 0]
+        ang = rng.uniform(-np.pi, np.pi)
+        d = rng.uniform(6, 15)
+        e.state_final = [e.state_start[0] + d * np.cos(ang), e.state_start[1] + d * np.sin(ang), ang, 0, 0]
+        n = int(rng.integers(1, 5))
+        obs = []
+        for _ in range(n):
+            s_ = rng.uniform(0.1, 0.9)
+            off = rng.uniform(-3.0, 3.0)
+            obs.append([e.state_start[0] + s_ * d * np.cos(ang) - off * np.sin(ang),
+                        e.state_start[1] + s_ * d * np.sin(ang) + off * np.cos(ang),
+                        rng.uniform(0.3, 1.5), rng.uniform(0.1, 0.6)])
+        e.obstacles = obs
+        e.verbose = False
+        egos.append(e)
+    host = bt.pack_problems(egos, sim)                          # the scalar loop, the reference's operations
+    lib_ = bt.pack_problems(egos, sim, device_guess="all")
+    g = lib_.guess()
+    assert g.shape == host.xguess.shape
+    assert np.abs(g - host.xguess).max() < 1e-12
+    moved = np.abs(g[:, :2] - bt.library_guess(lib_.pdata, None, lib_.N)[:, :2]).max(axis=(0, 1)) > 1e-9
+    assert moved.sum() > 20                                     # the obstacle branch did something in many problems
+    # one obstacle each, vectorised host path: same shift branch bit for bit, push branch to rounding
+    start, goal, obs = random_start_goal(500, seed=5, with_obstacle=True)
+    a = bt.pack_arrays(start, goal, 5.0, obstacle=obs)
+    b = bt.pack_arrays(start, goal, 5.0, obstacle=obs, device_guess="all")
+    assert b.xguess is None and np.abs(b.guess() - a.xguess).max() < 1e-12
 
 
 def test_no_silent_cpu_fallback():
