@@ -285,6 +285,31 @@ static void rk4_sens(const problem *pb, const real *x, const real *u,
 }
 
 static int g_stage0_rows = 0;      /* MPCX_ORACLE_STAGE0_ROWS, see linearize() */
+/* MPCX_ORACLE_COND_BLOCKS (study only): emulates HPIPM's partial condensing to this many blocks
+ * (reference core_solver.py:248 selects 5).  In exact arithmetic an interior-point method on the
+ * condensed QP takes the steps of the stage-wise method IF the latter starts from states that satisfy
+ * the dynamics inside every block, and its stopping test sees the multipliers of the eliminated
+ * dynamics rows at their optimal values.  So: (i) the cold start propagates the states through each
+ * block from the block's first state (states inside a block are no optimisation variables there and
+ * are not moved into their boxes: those rows are general constraints of the condensed QP), (ii) the
+ * multipliers of the dynamics rows inside a block are recomputed in every residual evaluation so that
+ * the stationarity of the eliminated states holds exactly. */
+static int g_cond_blocks = 0;
+static inline int block_start(const problem *pb, int k)
+{
+    if (g_cond_blocks <= 0) return 1;
+    const int N = pb->N, nb = g_cond_blocks;
+    if (k == 0 || k >= N) return 1;
+    /* HPIPM's partition: N / nb stages per block, the first N % nb blocks one longer */
+    const int q = N / nb, rmd = N % nb;
+    int start = 0;
+    for (int j = 0; j < nb; ++j) {
+        if (k == start) return 1;
+        start += q + (j < rmd ? 1 : 0);
+        if (start > k) return 0;
+    }
+    return 1;
+}
 
 /* ------------------------------------------------------------------ */
 /* linearisation of one SQP iteration                                   */
@@ -422,7 +447,8 @@ static void qp_residuals(const problem *pb, stage *st, int m_total, qp_res *R)
             for (int c = 0; c < NX; ++c)
                 for (int i = 0; i < NX; ++i) s->rg[NU + c] = rfma(s->A[i][c], pn[i], s->rg[NU + c]);
         }
-        if (k > 0)
+        const int eliminate = (k > 0) && !block_start(pb, k);      /* study switch, see g_cond_blocks */
+        if (k > 0 && !eliminate)
             for (int i = 0; i < NX; ++i) s->rg[NU + i] = s->rg[NU + i] - s->qpi[i];
         real ssum = 0.0;     /* complementarity products of this stage, then added to the total */
         for (int r = s->r0; r < s->r1; ++r) {
@@ -445,6 +471,8 @@ static void qp_residuals(const problem *pb, stage *st, int m_total, qp_res *R)
             ssum = ssum + mu_;
         }
         sum = sum + ssum;
+        if (eliminate)
+            for (int i = 0; i < NX; ++i) { s->qpi[i] = s->rg[NU + i]; s->rg[NU + i] = (real)0.0; }
         int j0 = (k == N) ? NU : 0, j1 = (k == 0) ? NU : NZ;
         for (int j = j0; j < j1; ++j) ng = rmax(ng, rabs(s->rg[j]));
         if (k < N) {
@@ -474,11 +502,21 @@ static void qp_init(const problem *pb, const mpcx_opts *o, stage *st)
         for (int i = 0; i < NX; ++i) s->qpi[i] = (real)0.0;
         if (k == 0)
             for (int i = 0; i < NX; ++i) s->v[NU + i] = pb->x0[i] - s->x[i];
+        const int inside = !block_start(pb, k);
+        if (inside) {      /* study switch: the state follows from the stage before */
+            const stage *p = &st[k - 1];
+            for (int i = 0; i < NX; ++i) {
+                real acc = p->b[i];
+                for (int j = 0; j < NX; ++j) acc = rfma(p->A[i][j], p->v[NU + j], acc);
+                for (int c = 0; c < NU; ++c) acc = rfma(p->B[i][c], p->v[c], acc);
+                s->v[NU + i] = acc;
+            }
+        }
         for (int r = s->r0; r < s->r1; ++r) {
             if (!((s->rmask >> r) & 1u)) continue;
             real dl = lo[r] - s->c[r], du = up[r] - s->c[r];
             real tl, tu;
-            if (r < ROW_G0) {
+            if (r < ROW_G0 && !(inside && r >= NU)) {
                 tl = s->v[r] - dl;
                 tu = du - s->v[r];
                 if (tl < thr0) {
@@ -980,6 +1018,7 @@ int mpcx_oracle_solve_batch(const mpcx_batch *in, const mpcx_opts *o, mpcx_resul
     if (!in || !o || !out || in->N < 1 || b0 < 0 || b1 > in->B) return MPCX_E_BADARG;
     g_debug = getenv("MPCX_ORACLE_DEBUG") ? atoi(getenv("MPCX_ORACLE_DEBUG")) : 0;
     g_stage0_rows = getenv("MPCX_ORACLE_STAGE0_ROWS") ? atoi(getenv("MPCX_ORACLE_STAGE0_ROWS")) : 0;
+    g_cond_blocks = getenv("MPCX_ORACLE_COND_BLOCKS") ? atoi(getenv("MPCX_ORACLE_COND_BLOCKS")) : 0;
     const int N = in->N, B = in->B;
     int fail = 0;
 #ifdef _OPENMP

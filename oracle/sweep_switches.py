@@ -86,6 +86,18 @@ AROUND_LM = [
                                       qp_tol_stat=1e-6, qp_tol_eq=1e-6, qp_tol_ineq=1e-6, qp_tol_comp=1e-6), 0),
 ]
 
+# third table: the adopted setting with HPIPM's partial condensing emulated (study switch of the oracle:
+# cold start consistent with the dynamics inside each block, multipliers of the eliminated dynamics rows
+# at their optimal values in the stopping test; reference core_solver.py:248 selects 5 blocks)
+ADOPTED = dict(lm_scale_by_h=1, qp_tol_stat=1e-6, qp_tol_eq=1e-8, qp_tol_ineq=1e-8, qp_tol_comp=1e-6)
+CONDENSING = [
+    ("adopted defaults (stage-wise, no condensing)", ADOPTED, 0),
+    ("+ partial condensing to 5 blocks, emulated", ADOPTED, {"MPCX_ORACLE_COND_BLOCKS": "5"}),
+    ("+ partial condensing to 10 blocks, emulated", ADOPTED, {"MPCX_ORACLE_COND_BLOCKS": "10"}),
+    ("+ full condensing (1 block), emulated", ADOPTED, {"MPCX_ORACLE_COND_BLOCKS": "1"}),
+    ("round-1 setting + partial condensing to 5 blocks", {}, {"MPCX_ORACLE_COND_BLOCKS": "5"}),
+]
+
 
 def opts_with(changes):
     o = oracle_lib.default_opts()
@@ -147,6 +159,7 @@ def main():
     ap.add_argument("--quick", action="store_true", help="8 grid poses, 2 000 benchmark problems")
     ap.add_argument("--threads", type=int, default=min(8, os.cpu_count() or 1))
     ap.add_argument("--around-lm", action="store_true", help="the second table: switches around lm_scale_by_h = 1")
+    ap.add_argument("--condensing", action="store_true", help="the third table: partial condensing emulated")
     args = ap.parse_args()
     n_head = 2000 if args.quick else 20000
     lib = oracle_lib.load(oracle_lib.ORACLE_FAST_SO if os.path.exists(oracle_lib.ORACLE_FAST_SO) else oracle_lib.ORACLE_SO)
@@ -154,11 +167,14 @@ def main():
     print("| setting | max abs diff to the 28 recorded numbers | line: gap, SQP / IP it. | E_to_F: gap, SQP / IP it. | grid ok | segments ok | B_to_C terminal faces | benchmark status mix 0/1/2/3/4 | converged | mean IP it. | mean SQP it. |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")
     t0 = time.time()
-    for name, changes, stage0 in (AROUND_LM if args.around_lm else SETTINGS):
-        if stage0:
+    study_env = ("MPCX_ORACLE_STAGE0_ROWS", "MPCX_ORACLE_COND_BLOCKS")
+    for name, changes, stage0 in (CONDENSING if args.condensing else AROUND_LM if args.around_lm else SETTINGS):
+        for k in study_env:
+            os.environ.pop(k, None)
+        if isinstance(stage0, dict):
+            os.environ.update(stage0)
+        elif stage0:
             os.environ["MPCX_ORACLE_STAGE0_ROWS"] = str(stage0)
-        else:
-            os.environ.pop("MPCX_ORACLE_STAGE0_ROWS", None)
         o = opts_with(changes)
         worst, per = pin_gap(o, solver)
         grid_ok, grid_n, seg_ok, face = outcome_pins(o, solver, args.quick)
@@ -167,7 +183,8 @@ def main():
         print(f"| {name} | {worst:.2e} | {cell(per['line'])} | {cell(per['E_to_F'])} | {grid_ok}/{grid_n} | {seg_ok}/5 | "
               f"{'%.1e' % face if face is not None else 'B_to_C failed'} | {'/'.join(str(int(v)) for v in mix)} | {conv:.4f} | {ipm:.1f} | {sqp:.2f} |")
         sys.stdout.flush()
-    os.environ.pop("MPCX_ORACLE_STAGE0_ROWS", None)
+    for k in study_env:
+        os.environ.pop(k, None)
     print(f"\n{n_head} benchmark problems per setting; {time.time() - t0:.0f} s on {args.threads} threads.")
 
 

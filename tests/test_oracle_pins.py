@@ -119,3 +119,24 @@ def test_start_inside_constraints_fails_like_an_infeasible_qp(oracle):
     assert all(15 <= q <= 50 for q in qp)
     for ego, sim in pairs:
         assert find_path(ego, sim, solver=oracle.solve_packed) is None
+
+
+def test_partial_condensing_emulated_changes_no_outcome(oracle, monkeypatch):
+    """The reference selects HPIPM's partial condensing to 5 blocks (core_solver.py:248); the solver here
+    recurses stage by stage.  The oracle's study switch gives the stage-wise method the condensed
+    method's cold start and stopping test (what distinguishes the two in exact arithmetic): the recorded
+    numbers are met as before and a benchmark sample ends with the same statuses and SQP counts."""
+    from mpc_amd.synthetic import synthetic_batch
+    sample = synthetic_batch(1500)
+    plain = oracle.solve_packed(sample)
+    monkeypatch.setenv("MPCX_ORACLE_COND_BLOCKS", "5")
+    for name in ("line", "E_to_F"):
+        (status, res), pin = _solve(name, oracle), PINS[name]
+        assert status == pin["status"]
+        assert np.abs(res["x"][1] - pin["x1"]).max() < TOL and np.abs(res["x"][-1] - pin["xN"]).max() < TOL
+        assert np.abs(res["u"][0] - pin["u0"]).max() < TOL and np.abs(res["u"][-1] - pin["u_last"]).max() < TOL
+    cond = oracle.solve_packed(sample)
+    assert np.array_equal(cond["status"], plain["status"]) and np.array_equal(cond["sqp_iter"], plain["sqp_iter"])
+    ok = plain["status"] == 0
+    assert np.abs(cond["X"][ok] - plain["X"][ok]).max() < 1e-5
+    assert not np.array_equal(cond["qp_iter"], plain["qp_iter"])      # the switch does change the path
