@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 105
+#define MPCX_VERSION 106
 
 #define MPCX_NX 5       /* state  [x, y, theta, v, delta]        (core_solver.py:131) */
 #define MPCX_NU 2       /* input  [acceleration, steering rate]  (core_solver.py:132) */
@@ -101,6 +101,20 @@ typedef struct mpcx_opts {
     int32_t max_obs;        /* largest n_obs[b] of the batch if known, -1 = unknown:
                                the host entry point then scans n_obs, the device
                                entry point assumes MPCX_MAX_OBS                      */
+    /* Globalisation.  0 (default): every SQP step is taken in full, which is what the reference
+     * runs (it sets no globalization, core_solver.py:242-253; acados' default is FIXED_STEP).
+     * 1: backtracking line search on the exact penalty function
+     *      phi(w) = f(w) + rho * max(|dynamics gaps|_inf, |violation of the inequality rows|_inf),
+     * rho = max(rho so far, ls_rho_factor * sum |multipliers of the QP|): the step length starts
+     * at 1 and is multiplied by ls_shrink until phi(w + a d) <= phi(w) - ls_c1 * a * rho *
+     * (infeasibility at w) or a would fall below ls_alpha_min (that length is then taken); the
+     * multipliers always take the full step.  No counterpart in the reference: parity unpinned.  */
+    int32_t globalization;
+    int32_t reserved_;      /* keeps the doubles below aligned; must be 0 */
+    double  ls_shrink;      /* 0.5   */
+    double  ls_alpha_min;   /* 1/64  */
+    double  ls_c1;          /* 1e-4  */
+    double  ls_rho_factor;  /* 2     */
 } mpcx_opts;
 
 typedef struct mpcx_result {

@@ -32,7 +32,10 @@ class MpcxOpts(C.Structure):
                 ("cond_pred_corr", C.c_int32),
                 ("mu0", C.c_double), ("thr0", C.c_double), ("alpha_min", C.c_double),
                 ("lam_min", C.c_double), ("t_min", C.c_double),
-                ("rti", C.c_int32), ("max_obs", C.c_int32)]
+                ("rti", C.c_int32), ("max_obs", C.c_int32),
+                ("globalization", C.c_int32), ("reserved_", C.c_int32),
+                ("ls_shrink", C.c_double), ("ls_alpha_min", C.c_double),
+                ("ls_c1", C.c_double), ("ls_rho_factor", C.c_double)]
 
 
 class MpcxResult(C.Structure):

@@ -228,6 +228,11 @@ void mpcx_opts_default(mpcx_opts *o)
     o->t_min = 1e-16;
     o->rti = 0;
     o->max_obs = -1;
+    o->globalization = 0;      /* full steps, as the reference */
+    o->ls_shrink = 0.5;
+    o->ls_alpha_min = 1.0 / 64.0;
+    o->ls_c1 = 1e-4;
+    o->ls_rho_factor = 2.0;
 }
 
 int mpcx_max_horizon(void)

@@ -734,8 +734,9 @@ struct LAcc { double rs, re, ri, rc, cost; };
 
 // nxt (single-problem mode only): state, step and multiplier of stage k+1, read by the caller
 // before any lane has overwritten them; otherwise they are loaded here
+// alpha: length of the SQP step (1 unless the line search shortened it; 1 * v is v exactly)
 template <int NH, int KIND, bool COOP = false>
-DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, bool first,
+DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, bool first, double alpha,
                  double *xk, double *pik, LAcc &a, const KR &kr = KR{false, false}, const double *nxt = nullptr)
 {
     typedef Map<NH> M;
@@ -769,12 +770,12 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
     if (KIND != LAST) {
 #pragma unroll
         for (int c = 0; c < NU; ++c) {
-            uk[c] = first ? uk[c] : uk[c] + vu[c];
+            uk[c] = first ? uk[c] : uk[c] + alpha * vu[c];
             uk[c] = is_last<KIND>(kr) ? 0.0 : uk[c];
             stw<KIND>(L, k, M::U + c, uk[c]);
         }
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xn1[i] = first ? xn1[i] : xn1[i] + vxn1[i];
+        for (int i = 0; i < NX; ++i) xn1[i] = first ? xn1[i] : xn1[i] + alpha * vxn1[i];
         double xn[NX];
         rk4_sens(L, xk, uk, xn, ab);
         store_ab<NH, KIND>(L, k, ab);
@@ -896,7 +897,8 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
 // allocation; arguments travel by value in registers and results come back through a
 // small per-lane LDS area `ret` ([slot][lane] doubles), never through the stack.
 template <int NH>
-__device__ __attribute__((noinline)) void sweep_L(Lane L, PC<NH> pc, const mpcx_opts *op, bool first, ldouble *ret)
+__device__ __attribute__((noinline)) void sweep_L(Lane L, PC<NH> pc, const mpcx_opts *op, bool first, double alpha,
+                                                  ldouble *ret)
 {
     const mpcx_opts &o = *op;
     typedef Map<NH> M;
@@ -906,14 +908,124 @@ __device__ __attribute__((noinline)) void sweep_L(Lane L, PC<NH> pc, const mpcx_
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         double x0 = ldw<MID>(L, 0, M::X + i), v0 = ldw<MID>(L, 0, M::V + NU + i);
-        xk[i] = first ? x0 : x0 + v0;
+        xk[i] = first ? x0 : x0 + alpha * v0;
         pik[i] = 0.0;
     }
-    stage_L<NH, FIRST>(L, o, pc, 0, first, xk, pik, a);
-    for (int k = 1; k < N; ++k) stage_L<NH, MID>(L, o, pc, k, first, xk, pik, a);
-    stage_L<NH, LAST>(L, o, pc, N, first, xk, pik, a);
+    stage_L<NH, FIRST>(L, o, pc, 0, first, alpha, xk, pik, a);
+    for (int k = 1; k < N; ++k) stage_L<NH, MID>(L, o, pc, k, first, alpha, xk, pik, a);
+    stage_L<NH, LAST>(L, o, pc, N, first, alpha, xk, pik, a);
     ret[0 * 64] = a.rs; ret[1 * 64] = a.re; ret[2 * 64] = a.ri; ret[3 * 64] = a.rc;
     ret[4 * 64] = a.cost;
+}
+
+// ---------------------------------------------------------------------------
+// sweep M (forward, reads only): the line search's look at w + alpha * d, d = the primal solution
+// of the QP just solved (mpcx_opts.globalization = 1): objective, largest dynamics gap, largest
+// violation of an inequality row (and of the initial state), and the sum of the absolute values of
+// the QP's multipliers.  Sums per stage first, then over the stages in ascending order.
+// ---------------------------------------------------------------------------
+struct MAcc { double cost, gap, viol, msum; };
+
+template <int NH, int KIND, bool COOP = false>
+DEV void stage_M(const Lane &L, const PC<NH> &pc, int k, double alpha, double *xk, MAcc &a,
+                 const KR &kr = KR{false, false}, const double *nxt = nullptr, const double *qk = nullptr)
+{
+    typedef Map<NH> M;
+    double uk[NU] = {0.0, 0.0}, xn1[NX], qpi[NX], ll[M::R], lu[M::R];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { xn1[i] = 0.0; qpi[i] = 0.0; }
+    if (KIND != LAST) {
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            const double u0 = ldw<KIND>(L, k, M::U + c), vu = ldw<KIND>(L, k, M::V + c);
+            uk[c] = is_last<KIND>(kr) ? 0.0 : u0 + alpha * vu;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double x1 = COOP ? nxt[i] : ldw<KIND>(L, k + 1, M::X + i);
+            const double v1 = COOP ? nxt[NX + i] : ldw<KIND>(L, k + 1, M::V + NU + i);
+            xn1[i] = x1 + alpha * v1;
+        }
+    }
+    if (KIND != FIRST) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) qpi[i] = COOP ? qk[i] : ldw<KIND>(L, k, M::QPI + i);
+    }
+#pragma unroll
+    for (int r = 0; r < M::R; ++r) {
+        ll[r] = 0.0; lu[r] = 0.0;
+        if (!row_present<KIND>(r)) continue;
+        ll[r] = ldw<KIND>(L, k, M::LAML + r);
+        lu[r] = ldw<KIND>(L, k, M::LAMU + r);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double ck = 0.0, cke = 0.0;
+    if (KIND != LAST) {
+        double xn[NX];
+        AB ab = {};
+        rk4_sens(L, xk, uk, xn, ab);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) a.gap = is_last<KIND>(kr) ? a.gap : dmax(a.gap, dabs(xn[i] - xn1[i]));
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) {
+            double z = (j < NU) ? uk[j] : (xk[j - NU] - pc.get(C_GOAL + j - NU));
+            double hw = (0.5 * L.h) * pc.get(C_W + j);
+            ck = fma(hw * z, z, ck);
+        }
+    }
+    if (KIND == LAST || KIND == ANY) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double z = xk[i] - pc.get(C_GOAL + i);
+            cke = fma((0.5 * pc.get(C_WE + i)) * z, z, cke);
+        }
+    }
+    a.cost = a.cost + (is_last<KIND>(kr) ? cke : ck);
+    if (KIND == FIRST || KIND == ANY) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double d0 = dabs(pc.get(C_X0 + i) - xk[i]);
+            a.viol = is_first<KIND>(kr) ? dmax(a.viol, d0) : a.viol;
+        }
+    }
+    double sk = 0.0;
+    if (KIND != FIRST) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) sk = is_first<KIND>(kr) ? sk : sk + dabs(qpi[i]);
+    }
+#pragma unroll
+    for (int r = 0; r < M::R; ++r) {
+        if (!row_present<KIND>(r)) continue;
+        const bool pr = row_on<KIND>(kr, r) && ((r < 9) || (r - 9 < L.nobs));
+        double c, jx, jy, lo, up;
+        row_geom<NH>(pc, r, xk, uk, c, jx, jy);
+        row_bounds<NH, KIND>(L, pc, kr, r, lo, up);
+        const double vv = dmax(dmax(a.viol, lo - c), c - up);
+        a.viol = pr ? vv : a.viol;
+        const double s2 = (sk + dabs(ll[r])) + dabs(lu[r]);
+        sk = pr ? s2 : sk;
+    }
+    a.msum = a.msum + sk;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xk[i] = xn1[i];
+}
+
+template <int NH>
+__device__ __attribute__((noinline)) void sweep_M(Lane L, PC<NH> pc, double alpha, ldouble *ret)
+{
+    typedef Map<NH> M;
+    const int N = L.N;
+    MAcc a = {0.0, 0.0, 0.0, 0.0};
+    double xk[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const double x0 = ldw<MID>(L, 0, M::X + i), v0 = ldw<MID>(L, 0, M::V + NU + i);
+        xk[i] = x0 + alpha * v0;
+    }
+    stage_M<NH, FIRST>(L, pc, 0, alpha, xk, a);
+    for (int k = 1; k < N; ++k) stage_M<NH, MID>(L, pc, k, alpha, xk, a);
+    stage_M<NH, LAST>(L, pc, N, alpha, xk, a);
+    ret[0 * 64] = a.cost; ret[1 * 64] = a.gap; ret[2 * 64] = a.viol; ret[3 * 64] = a.msum;
 }
 
 // ---------------------------------------------------------------------------
@@ -2583,7 +2695,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
 // sweep L has no recursion: every stage is linearised at its own (new) state, which its lane
 // forms from the stage's own iterate and step exactly as the stage before would have
 template <int NH, bool ONE>
-__device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, const mpcx_opts *op, bool first, ldouble *ret)
+__device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, const mpcx_opts *op, bool first, double alpha, ldouble *ret)
 {
     typedef Map<NH> M;
     COOP_UNPACK(NH);
@@ -2603,7 +2715,7 @@ __device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, const mpcx_opts *o
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const double x0 = ldw<ANY>(S, 0, M::X + i), v0 = ldw<ANY>(S, 0, M::V + NU + i), q0 = ldw<ANY>(S, 0, M::QPI + i);
-                xk[i] = first ? x0 : x0 + v0;
+                xk[i] = first ? x0 : x0 + alpha * v0;
                 pik[i] = (kj > 0) ? q0 : 0.0;
             }
         }
@@ -2619,7 +2731,7 @@ __device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, const mpcx_opts *o
         coop_sync();
         LAcc a = {0.0, 0.0, 0.0, 0.0, 0.0};
         const KR kr = {kj == 0, kj == N};
-        if (kj <= N) stage_L<NH, ANY, true>(S, o, pc, 0, first, xk, pik, a, kr, nxt);
+        if (kj <= N) stage_L<NH, ANY, true>(S, o, pc, 0, first, alpha, xk, pik, a, kr, nxt);
         const int kend = (N - k0 < 63) ? N - k0 : 63;
         tot.rs = dmax(tot.rs, wave_max(a.rs)); tot.re = dmax(tot.re, wave_max(a.re));
         tot.ri = dmax(tot.ri, wave_max(a.ri)); tot.rc = dmax(tot.rc, wave_max(a.rc));
@@ -2635,6 +2747,60 @@ __device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, const mpcx_opts *o
     }
     ret[0 * 64] = tot.rs; ret[1 * 64] = tot.re; ret[2 * 64] = tot.ri; ret[3 * 64] = tot.rc;
     ret[4 * 64] = tot.cost;
+}
+
+// sweep M of one problem, a lane per stage (the line search's look at a trial point, see stage_M)
+template <int NH, bool ONE>
+__device__ __attribute__((noinline)) void coop_M(COOP_PARAMS, double alpha, ldouble *ret)
+{
+    typedef Map<NH> M;
+    COOP_UNPACK(NH);
+    const int N = C.N;
+    const int j = (int)threadIdx.x;
+    coop_sync();
+    MAcc tot = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; ONE ? (k0 == 0) : (k0 <= N); k0 += 64) {
+        const int kj = k0 + j;
+        const Lane S = stage_lane(C, (unsigned)kj);
+        double xk[NX], qk[NX], nxt[2 * NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xk[i] = 0.0; qk[i] = 0.0; nxt[i] = nxt[NX + i] = 0.0; }
+        if (kj <= N) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const double x0 = ldw<ANY>(S, 0, M::X + i), v0 = ldw<ANY>(S, 0, M::V + NU + i);
+                xk[i] = x0 + alpha * v0;
+                qk[i] = ldw<ANY>(S, 0, M::QPI + i);
+            }
+        }
+        if (kj < N) {
+            const Lane S1 = stage_lane(C, (unsigned)kj + 1u);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                nxt[i] = ldw<ANY>(S1, 0, M::X + i);
+                nxt[NX + i] = ldw<ANY>(S1, 0, M::V + NU + i);
+            }
+        }
+        MAcc a = {0.0, 0.0, 0.0, 0.0};
+        const KR kr = {kj == 0, kj == N};
+        if (kj <= N) stage_M<NH, ANY, true>(S, pc, 0, alpha, xk, a, kr, nxt, qk);
+        const int kend = (N - k0 < 63) ? N - k0 : 63;
+        tot.gap = dmax(tot.gap, wave_max(a.gap));
+        tot.viol = dmax(tot.viol, wave_max(a.viol));
+        {
+            // the two sums: chains from the block's first stage up to stage kend
+            const double s1 = tot.cost, s2 = tot.msum;
+            double c1 = s1, c2 = s2;
+            for (int s = 0; s <= kend; ++s) {
+                const double i1 = lane_below<ONE>(c1, s1), i2 = lane_below<ONE>(c2, s2);
+                c1 = (j <= kend) ? i1 + a.cost : i1;
+                c2 = (j <= kend) ? i2 + a.msum : i2;
+            }
+            tot.cost = bcast(c1, kend);
+            tot.msum = bcast(c2, kend);
+        }
+    }
+    ret[0 * 64] = tot.cost; ret[1 * 64] = tot.gap; ret[2 * 64] = tot.viol; ret[3 * 64] = tot.msum;
 }
 
 // ---------------------------------------------------------------------------
@@ -2693,6 +2859,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     bool first = true, fresh = false;
     double res[4] = {0.0, 0.0, 0.0, 0.0};
     double cost = 0.0;
+    double ls_rho = 0.0;      // line search (mpcx_opts.globalization): penalty weight of this lane's problem
     Step sp;
     sp.have = false; sp.mode = 0; sp.sigma_mu = 0.0; sp.alpha = 0.0;
 
@@ -2715,14 +2882,43 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             qp_it = 0;
         }
     };
+    // Line search (globalization = 1), one trial: (c, re, ri, ms) = sweep M at step length alpha; rho, phi0
+    // are set by the first trial.  Returns true when alpha is taken, else alpha has been shortened.
+    auto ls_trial = [&](int trial, double c, double re, double ri, double ms, double cost0, double viol0,
+                        double &rho, double &phi0, double &alpha) -> bool {
+        if (trial == 0) {
+            const double want = o.ls_rho_factor * ms;
+            if (want > rho) rho = want;
+            phi0 = fma(rho, viol0, cost0);
+        }
+        const double phi = fma(rho, dmax(re, ri), c);
+        if (phi <= phi0 - ((o.ls_c1 * alpha) * rho) * viol0) return true;
+        if (alpha * o.ls_shrink < o.ls_alpha_min) return true;
+        alpha = alpha * o.ls_shrink;
+        return false;
+    };
     // sweep L of the problem of lane p, the wavefront with a lane per stage; results into lane p
     auto single_L = [&](int p) {
         Lane C;
         PC<NH> pcc;
         problem_of_lane<NH>(L, pc, (ldouble *)pc_lds, p, C, pcc);
         const bool fp = __builtin_amdgcn_readlane((int)first, p) != 0;
-        if (N < 64) coop_L<NH, true>(COOP_PASS(C, pcc), op, fp, ret);
-        else coop_L<NH, false>(COOP_PASS(C, pcc), op, fp, ret);
+        double alpha = 1.0;
+        if (o.globalization && !o.rti && !fp) {
+            // the step of the QP just solved is tried at shorter and shorter lengths
+            double rho = bcast(ls_rho, p), phi0 = 0.0;
+            const double cost0 = bcast(cost, p), viol0 = dmax(bcast(res[1], p), bcast(res[2], p));
+            for (int trial = 0;; ++trial) {
+                if (N < 64) coop_M<NH, true>(COOP_PASS(C, pcc), alpha, ret);
+                else coop_M<NH, false>(COOP_PASS(C, pcc), alpha, ret);
+                const double c = uniform(ret[0 * 64]), re = uniform(ret[1 * 64]), ri = uniform(ret[2 * 64]),
+                             ms = uniform(ret[3 * 64]);
+                if (ls_trial(trial, c, re, ri, ms, cost0, viol0, rho, phi0, alpha)) break;
+            }
+            if ((int)threadIdx.x == p) ls_rho = rho;
+        }
+        if (N < 64) coop_L<NH, true>(COOP_PASS(C, pcc), op, fp, alpha, ret);
+        else coop_L<NH, false>(COOP_PASS(C, pcc), op, fp, alpha, ret);
         const double r0 = uniform(ret[0 * 64]), r1 = uniform(ret[1 * 64]), r2 = uniform(ret[2 * 64]),
                      r3 = uniform(ret[3 * 64]), r4 = uniform(ret[4 * 64]);
         // (the second sweep L of a real-time iteration only applies the step and reports the objective:
@@ -2988,6 +3184,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                         status = MPCX_MAXITER;
                         sqp_it = 0;
                         qp_total = 0;
+                        ls_rho = 0.0;
                         first = true;
                         state = LS_LIN;
                         fresh = true;
@@ -3047,18 +3244,36 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                 for (unsigned long long rest = single_mask; rest != 0; rest &= rest - 1) single_L(__ffsll((long long)rest) - 1);
                 coop_sync();      // what the stage lanes stored is visible to the problems' own lanes
             }
+            double step_alpha = 1.0;
+            if (o.globalization && !o.rti) {
+                // line search of the lanes whose sweep L runs one lane per problem: sweep M reads only,
+                // so the lanes still searching repeat it while the others sit out
+                bool searching = (state == LS_LIN) && !first && !coop_lin && !solo;
+                double rho = ls_rho, phi0 = 0.0;
+                const double cost0 = cost, viol0 = dmax(res[1], res[2]);
+                for (int trial = 0; __any(searching); ++trial) {
+                    if (searching) {
+                        sweep_M<NH>(L, pc, step_alpha, ret);
+                        if (ls_trial(trial, ret[0 * 64], ret[1 * 64], ret[2 * 64], ret[3 * 64], cost0, viol0, rho, phi0,
+                                     step_alpha)) {
+                            searching = false;
+                            ls_rho = rho;
+                        }
+                    }
+                }
+            }
             if (state == LS_LIN) {
                 if (o.rti && !first) {
                     // real-time iteration: apply the one step, report the new objective
                     if (!coop_lin && !solo) {
-                        sweep_L<NH>(L, pc, op, false, ret);
+                        sweep_L<NH>(L, pc, op, false, 1.0, ret);
                         cost = ret[4 * 64];
                     }
                     status = MPCX_SUCCESS;
                     state = LS_OUT;
                 } else {
                     if (!coop_lin && !solo) {
-                        sweep_L<NH>(L, pc, op, first, ret);
+                        sweep_L<NH>(L, pc, op, first, step_alpha, ret);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) res[i] = ret[i * 64];
                         cost = ret[4 * 64];

@@ -379,6 +379,17 @@ static int g_debug = 0;
 
 static inline real rmax(real a, real b) { return (b > a) ? b : a; }
 
+/* value of row r at (x, u), as linearize() forms it */
+static inline real row_value(const problem *pb, int r, const real *x, const real *u)
+{
+    if (r < NU) return u[r];
+    if (r < ROW_G0) return x[r - NU];
+    if (r < 9) return rfma(pb->cg[r - ROW_G0][1], x[1], pb->cg[r - ROW_G0][0] * x[0]);
+    const real *ob = pb->obs[r - 9];
+    real dx = x[0] - ob[0], dy = x[1] - ob[1];
+    return rfma(dy, dy, dx * dx) - ob[2];
+}
+
 /* NLP residuals at (x,u,pi,lam) with the current linearisation.
  * res[0] stationarity, [1] dynamics gap, [2] inequality violation, [3] complementarity */
 static void nlp_residuals(const problem *pb, const stage *st, real res[4])
@@ -896,11 +907,84 @@ static real nlp_cost(const problem *pb, const stage *st)
 
 typedef struct { int status, sqp_iter, qp_iter; real cost, res[4]; } outcome;
 
+/* Line search (mpcx_opts.globalization = 1): objective, largest dynamics gap and largest violation of
+ * an inequality row at w + alpha * d, d = the QP's primal solution; *msum = sum of the absolute values
+ * of the QP's multipliers (dynamics rows and both sides of the inequality rows).  Nothing is changed.
+ * Order of the sums: per stage, then over the stages in ascending order. */
+static void merit_eval(const problem *pb, const stage *st, real alpha, real *cost, real *re, real *ri, real *msum)
+{
+    const int N = pb->N;
+    real c = 0.0, gap = 0.0, viol = 0.0, ms = 0.0;
+    real xk[NX], xn1[NX] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < NX; ++i) xk[i] = st[0].x[i] + alpha * st[0].v[NU + i];
+    for (int k = 0; k <= N; ++k) {
+        const stage *s = &st[k];
+        real uk[NU] = {0.0, 0.0};
+        if (k < N) {
+            for (int cc = 0; cc < NU; ++cc) uk[cc] = s->u[cc] + alpha * s->v[cc];
+            for (int i = 0; i < NX; ++i) xn1[i] = st[k + 1].x[i] + alpha * st[k + 1].v[NU + i];
+            real xn[NX], A[NX][NX], B[NX][NU];
+            rk4_sens(pb, xk, uk, xn, A, B);
+            for (int i = 0; i < NX; ++i) gap = rmax(gap, rabs(xn[i] - xn1[i]));
+            real ck = 0.0;
+            for (int j = 0; j < NZ; ++j) {
+                real z = (j < NU) ? uk[j] : (xk[j - NU] - pb->goal[j - NU]);
+                real hw = ((real)0.5 * pb->h) * pb->W[j];
+                ck = rfma(hw * z, z, ck);
+            }
+            c = c + ck;
+        } else {
+            real ce = 0.0;
+            for (int i = 0; i < NX; ++i) {
+                real z = xk[i] - pb->goal[i];
+                ce = rfma(((real)0.5 * pb->We[i]) * z, z, ce);
+            }
+            c = c + ce;
+        }
+        if (k == 0)
+            for (int i = 0; i < NX; ++i) viol = rmax(viol, rabs(pb->x0[i] - xk[i]));
+        const real *lo = row_lo(pb, k), *up = row_up(pb, k);
+        real sk = 0.0;
+        if (k > 0) for (int i = 0; i < NX; ++i) sk = sk + rabs(s->qpi[i]);
+        for (int r = s->r0; r < s->r1; ++r) {
+            if (!((s->rmask >> r) & 1u)) continue;
+            real cv = row_value(pb, r, xk, uk);
+            viol = rmax(viol, lo[r] - cv);
+            viol = rmax(viol, cv - up[r]);
+            sk = sk + rabs(s->lam_l[r]);
+            sk = sk + rabs(s->lam_u[r]);
+        }
+        ms = ms + sk;
+        for (int i = 0; i < NX; ++i) xk[i] = xn1[i];
+    }
+    *cost = c; *re = gap; *ri = viol; *msum = ms;
+}
+
+static real line_search(const problem *pb, const mpcx_opts *o, const stage *st, real cost0, real viol0, real *rho)
+{
+    real alpha = 1.0;
+    real phi0 = 0.0;
+    for (int trial = 0;; ++trial) {
+        real c, re, ri, ms;
+        merit_eval(pb, st, alpha, &c, &re, &ri, &ms);
+        if (trial == 0) {
+            real want = (real)o->ls_rho_factor * ms;
+            if (want > *rho) *rho = want;
+            phi0 = rfma(*rho, viol0, cost0);
+        }
+        real phi = rfma(*rho, rmax(re, ri), c);
+        if (phi <= phi0 - (((real)o->ls_c1 * alpha) * *rho) * viol0) return alpha;
+        if (alpha * (real)o->ls_shrink < (real)o->ls_alpha_min) return alpha;
+        alpha = alpha * (real)o->ls_shrink;
+    }
+}
+
 static void sqp_solve(const problem *pb, const mpcx_opts *o, stage *st, outcome *out)
 {
     const int N = pb->N;
     int status = MPCX_MAXITER, it = 0, qp_total = 0;
     real res[4] = {0.0, 0.0, 0.0, 0.0};
+    real cost0 = 0.0, rho = 0.0;      /* line search: objective at the current iterate, penalty weight */
     for (int k = 0; k <= N; ++k) {
         for (int i = 0; i < NX; ++i) st[k].pi[i] = (real)0.0;
         for (int r = 0; r < MAXR; ++r) st[k].nl_l[r] = st[k].nl_u[r] = (real)0.0;
@@ -911,6 +995,7 @@ static void sqp_solve(const problem *pb, const mpcx_opts *o, stage *st, outcome 
 #endif
         linearize(pb, o, st);
         nlp_residuals(pb, st, res);
+        if (o->globalization) cost0 = nlp_cost(pb, st);
         if (!(r_isfinite(res[0]) && r_isfinite(res[1]) && r_isfinite(res[2]) && r_isfinite(res[3]))) {
             status = MPCX_NAN; break;
         }
@@ -931,10 +1016,12 @@ static void sqp_solve(const problem *pb, const mpcx_opts *o, stage *st, outcome 
         g_bucket = 0;
 #endif
         if (qs != 0 && qs != 1) { status = MPCX_QP_FAILURE; break; }
+        real alpha = 1.0;
+        if (o->globalization && !o->rti) alpha = line_search(pb, o, st, cost0, rmax(res[1], res[2]), &rho);
         for (int k = 0; k <= N; ++k) {
             stage *s = &st[k];
-            for (int i = 0; i < NX; ++i) s->x[i] = s->x[i] + s->v[NU + i];
-            if (k < N) for (int c = 0; c < NU; ++c) s->u[c] = s->u[c] + s->v[c];
+            for (int i = 0; i < NX; ++i) s->x[i] = s->x[i] + alpha * s->v[NU + i];
+            if (k < N) for (int c = 0; c < NU; ++c) s->u[c] = s->u[c] + alpha * s->v[c];
             if (k > 0) for (int i = 0; i < NX; ++i) s->pi[i] = s->qpi[i];
             for (int r = s->r0; r < s->r1; ++r)
                 if ((s->rmask >> r) & 1u) { s->nl_l[r] = s->lam_l[r]; s->nl_u[r] = s->lam_u[r]; }
@@ -1009,6 +1096,11 @@ void mpcx_oracle_opts_default(mpcx_opts *o)
     o->t_min = 1e-16;
     o->rti = 0;
     o->max_obs = -1;
+    o->globalization = 0;
+    o->ls_shrink = 0.5;
+    o->ls_alpha_min = 1.0 / 64.0;
+    o->ls_c1 = 1e-4;
+    o->ls_rho_factor = 2.0;
 }
 
 /* Solves problems [b0, b1) of the batch; nthreads > 1 uses OpenMP. */

@@ -16,7 +16,7 @@ import torch  # noqa: F401  first, so that the process has ONE HIP runtime (torc
 from mpc_amd import _lib
 from mpc_amd.batch import pack_problems
 from mpc_amd.core_solver import solve_groups
-from mpc_amd.synthetic import synthetic_batch
+from mpc_amd.synthetic import reachable_batch, synthetic_batch
 
 import cases
 
@@ -207,6 +207,33 @@ def test_sweep_modes_match_oracle(oracle, monkeypatch, duration, lanes):
     gpu = _lib.solve_packed(packed)
     ref = oracle.solve_packed(packed)
     cases.assert_same_solution(gpu, ref, f"N={packed.N} lanes={lanes}")
+
+
+@pytest.mark.parametrize("lanes", [None, 1, 3, 20, 64])
+def test_line_search_matches_oracle(oracle, monkeypatch, lanes):
+    """mpcx_opts.globalization = 1 (backtracking on the exact penalty function; the reference takes full
+    steps, so this has no counterpart there): device = oracle bit for bit through every scheduling path,
+    on batches where most steps are taken in full and on scenarios where the search shortens steps."""
+    if lanes is not None:
+        monkeypatch.setenv("MPCX_LANES", str(lanes))
+    opts = _lib.default_opts()
+    opts.globalization = 1
+    oopts = _lib.default_opts()
+    oopts.globalization = 1
+    for packed in (synthetic_batch(1500, seed=5), reachable_batch(600, seed=6), synthetic_batch(300, seed=7, obstacle=True)):
+        gpu = _lib.solve_packed(packed, opts=opts)
+        ref = oracle.solve_packed(packed, opts=oopts)
+        cases.assert_same_solution(gpu, ref, f"line search, lanes={lanes}")
+    if lanes in (None, 64):
+        changed = 0
+        for name in ("line", "B_to_C", "corner_turn", "u_turn"):      # N = 150 ... 400: blocks of 64 stages
+            ego, sim = cases.make_scenario(name)
+            p = pack_problems([ego], sim)
+            g = _lib.solve_packed(p, opts=opts)
+            r = oracle.solve_packed(p, opts=oopts)
+            cases.assert_same_solution(g, r, f"line search, {name}")
+            changed += int(r["sqp_iter"][0] != oracle.solve_packed(p)["sqp_iter"][0])
+        assert changed >= 1          # the search did shorten steps somewhere
 
 
 @pytest.mark.parametrize("burst", ["0", "1", "3", "8"])
