@@ -203,6 +203,38 @@ template <int KIND> DEV double ldw_lane(const Lane &L, int k, int f, int df)
     return *wsp(L, k, f, 512u * (unsigned)df);
 }
 
+// The options as the sweeps use them: fetched once per call into scalar registers (they are the same in
+// every lane).  Read through the pointer where they are used, they are fetched again after every store
+// the compiler cannot tell apart from them -- a dozen trips to the L2 per stage or per iteration, several
+// of them one after the other in the stopping tests, microseconds each on a busy GPU.  (What a sweep does
+// not use costs nothing: the copies are dropped with their loads.)
+DEV double sreg(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+DEV mpcx_opts opts_in_registers(const mpcx_opts *op)
+{
+    mpcx_opts o;
+    o.max_sqp_iter = __builtin_amdgcn_readfirstlane(op->max_sqp_iter);
+    o.max_qp_iter = __builtin_amdgcn_readfirstlane(op->max_qp_iter);
+    o.tol_stat = sreg(op->tol_stat); o.tol_eq = sreg(op->tol_eq); o.tol_ineq = sreg(op->tol_ineq); o.tol_comp = sreg(op->tol_comp);
+    o.qp_tol_stat = sreg(op->qp_tol_stat); o.qp_tol_eq = sreg(op->qp_tol_eq);
+    o.qp_tol_ineq = sreg(op->qp_tol_ineq); o.qp_tol_comp = sreg(op->qp_tol_comp);
+    o.lm = sreg(op->lm);
+    o.lm_scale_by_h = __builtin_amdgcn_readfirstlane(op->lm_scale_by_h);
+    o.cond_pred_corr = __builtin_amdgcn_readfirstlane(op->cond_pred_corr);
+    o.mu0 = sreg(op->mu0); o.thr0 = sreg(op->thr0); o.alpha_min = sreg(op->alpha_min);
+    o.lam_min = sreg(op->lam_min); o.t_min = sreg(op->t_min);
+    o.rti = __builtin_amdgcn_readfirstlane(op->rti);
+    o.max_obs = __builtin_amdgcn_readfirstlane(op->max_obs);
+    o.globalization = __builtin_amdgcn_readfirstlane(op->globalization);
+    o.reserved_ = 0;
+    o.ls_shrink = sreg(op->ls_shrink); o.ls_alpha_min = sreg(op->ls_alpha_min);
+    o.ls_c1 = sreg(op->ls_c1); o.ls_rho_factor = sreg(op->ls_rho_factor);
+    return o;
+}
+
 DEV double dabs(double a) { return (a < 0.0) ? -a : a; }
 DEV double dmax(double a, double b) { return (b > a) ? b : a; }
 DEV bool finite_d(double a) { return (a - a) == 0.0; }
@@ -900,7 +932,8 @@ template <int NH>
 __device__ __attribute__((noinline)) void sweep_L(Lane L, PC<NH> pc, const mpcx_opts *op, bool first, double alpha,
                                                   ldouble *ret)
 {
-    const mpcx_opts &o = *op;
+    const mpcx_opts ol = opts_in_registers(op);
+    const mpcx_opts &o = ol;
     typedef Map<NH> M;
     const int N = L.N;
     LAcc a = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1444,7 +1477,8 @@ template <int NH>
 __device__ __attribute__((noinline)) void sweep_B0(Lane L, PC<NH> pc, const mpcx_opts *op, bool sp_have, int sp_mode,
                                                    double sp_sigma_mu, double sp_alpha, int m_total, ldouble *ret)
 {
-    const mpcx_opts &o = *op;
+    const mpcx_opts ol = opts_in_registers(op);
+    const mpcx_opts &o = ol;
     Step sp;
     sp.have = sp_have; sp.mode = sp_mode; sp.sigma_mu = sp_sigma_mu; sp.alpha = sp_alpha;
     const int N = L.N;
@@ -1647,7 +1681,8 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, do
 template <int NH>
 __device__ __attribute__((noinline)) void sweep_Bs(Lane L, PC<NH> pc, const mpcx_opts *op, double sigma_mu)
 {
-    const mpcx_opts &o = *op;
+    const mpcx_opts ol = opts_in_registers(op);
+    const mpcx_opts &o = ol;
     const int N = L.N;
     double pn1[NX], pn2[NX];
 #pragma unroll
@@ -1895,7 +1930,8 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, dou
 template <int NH, int NS>
 __device__ __attribute__((noinline)) double sweep_F(Lane L, PC<NH> pc, const mpcx_opts *op, double sigma_mu, ldouble *ret)
 {
-    const mpcx_opts &o = *op;
+    const mpcx_opts ol = opts_in_registers(op);
+    const mpcx_opts &o = ol;
     const int N = L.N;
     FAcc a = {{1.0, 1.0}, 0.0, 0.0};
     double dx[NS][NX];
@@ -2148,10 +2184,11 @@ __device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, const mpcx_
                                                         double sp_sigma_mu, double sp_alpha, int k0, ldouble *ret)
 {
     COOP_UNPACK(NH);
-    const mpcx_opts &o = *op;
+    const mpcx_opts ol = opts_in_registers(op);
+    const mpcx_opts &o = ol;
     Step sp;
     sp.have = sp_have; sp.mode = sp_mode; sp.sigma_mu = sp_sigma_mu; sp.alpha = sp_alpha;
-    const int N = C.N;
+    const int N = __builtin_amdgcn_readfirstlane(C.N);      // (the same in every lane: loop counts in scalar registers)
     const int j = (int)threadIdx.x;
     ldouble *carry = ret - j + 5 * 64;      // same address in every lane
     const int kj = k0 + j;
@@ -2243,7 +2280,7 @@ __device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, const mpcx_
 template <int NH>
 DEV void coop_B0(const Lane &C, const PC<NH> &pc, const mpcx_opts *op, const Step &sp, int m_total, ldouble *ret)
 {
-    const int N = C.N;
+    const int N = __builtin_amdgcn_readfirstlane(C.N);      // (the same in every lane: loop counts in scalar registers)
     ldouble *carry = ret - threadIdx.x + 5 * 64;
     if (threadIdx.x < CY_N) carry[threadIdx.x] = 0.0;
     lds_order();
@@ -2265,8 +2302,9 @@ template <int NH, bool ONE>
 __device__ __attribute__((noinline)) void coop_Bs(COOP_PARAMS, const mpcx_opts *op, double sigma_mu)
 {
     COOP_UNPACK(NH);
-    const mpcx_opts &o = *op;
-    const int N = C.N;
+    const mpcx_opts ol = opts_in_registers(op);
+    const mpcx_opts &o = ol;
+    const int N = __builtin_amdgcn_readfirstlane(C.N);      // (the same in every lane: loop counts in scalar registers)
     const int j = (int)threadIdx.x;
     double c1[NX], c2[NX];          // p of the lowest stage of the block above, both systems
 #pragma unroll
@@ -2310,8 +2348,9 @@ template <int NH, int NS, bool ONE>
 __device__ __attribute__((noinline)) double coop_F(COOP_PARAMS, const mpcx_opts *op, double sigma_mu, ldouble *ret)
 {
     COOP_UNPACK(NH);
-    const mpcx_opts &o = *op;
-    const int N = C.N;
+    const mpcx_opts ol = opts_in_registers(op);
+    const mpcx_opts &o = ol;
+    const int N = __builtin_amdgcn_readfirstlane(C.N);      // (the same in every lane: loop counts in scalar registers)
     const int j = (int)threadIdx.x;
     double cdx[NS][NX];          // state step that enters the first stage of the block
 #pragma unroll
@@ -2407,8 +2446,9 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
     const int max_iters = qit_max >> 16;
     typedef Map<NH> M;
     COOP_UNPACK(NH);
-    const mpcx_opts &o = *op;
-    const int N = C.N;
+    const mpcx_opts ol = opts_in_registers(op);
+    const mpcx_opts &o = ol;
+    const int N = __builtin_amdgcn_readfirstlane(C.N);      // (the same in every lane: loop counts in scalar registers)
     const int j = (int)threadIdx.x;
     const int kj = j;
     const bool on = kj <= N;
@@ -2509,7 +2549,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             for (int s = 0; s <= kend; ++s) {
 #pragma unroll
                 for (int i = 0; i < NX; ++i) dxi[0][i] = lane_below<true>(dxo[0][i], 0.0);
-                if (kj < N) {
+                {      // (every lane: what stage N and the lanes without a stage produce is never used)
                     double du[NU];
                     F_rec(C, ld.ab, ld.kg, ld.kv[0], ld.rb, dxi[0], du, dxo[0]);
                 }
@@ -2619,7 +2659,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
                 for (int q = 0; q < 2; ++q) {
 #pragma unroll
                     for (int i = 0; i < NX; ++i) dxi[q][i] = lane_below<true>(dxo[q][i], 0.0);
-                    if (kj < N) {
+                    {      // (every lane, as in the affine sweep)
                         double du[NU];
                         F_rec(C, ld.ab, ld.kg, ld.kv[q], ld.rb, dxi[q], du, dxo[q]);
                     }
@@ -2699,8 +2739,9 @@ __device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, const mpcx_opts *o
 {
     typedef Map<NH> M;
     COOP_UNPACK(NH);
-    const mpcx_opts &o = *op;
-    const int N = C.N;
+    const mpcx_opts ol = opts_in_registers(op);
+    const mpcx_opts &o = ol;
+    const int N = __builtin_amdgcn_readfirstlane(C.N);      // (the same in every lane: loop counts in scalar registers)
     const int j = (int)threadIdx.x;
     coop_sync();
     LAcc tot = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -2755,7 +2796,7 @@ __device__ __attribute__((noinline)) void coop_M(COOP_PARAMS, double alpha, ldou
 {
     typedef Map<NH> M;
     COOP_UNPACK(NH);
-    const int N = C.N;
+    const int N = __builtin_amdgcn_readfirstlane(C.N);      // (the same in every lane: loop counts in scalar registers)
     const int j = (int)threadIdx.x;
     coop_sync();
     MAcc tot = {0.0, 0.0, 0.0, 0.0};
