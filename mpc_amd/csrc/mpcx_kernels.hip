@@ -2701,6 +2701,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
         if (done >= max_iters) break;
     }
     // ---- the stage goes back to the workspace: the iterate and the pending step, where the sweeps expect them ----
+    SUB_END(27);
     if (on) {
         const int sol = (sp.mode == 2) ? M::SOL2 : 0;
 #pragma unroll
@@ -2730,6 +2731,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
         carry[BR_DONE] = (double)done;
     }
     lds_order();
+    SUB_END(30);
 }
 
 // sweep L has no recursion: every stage is linearised at its own (new) state, which its lane
@@ -2958,8 +2960,10 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             }
             if ((int)threadIdx.x == p) ls_rho = rho;
         }
+        SUB_BEGIN();
         if (N < 64) coop_L<NH, true>(COOP_PASS(C, pcc), op, fp, alpha, ret);
         else coop_L<NH, false>(COOP_PASS(C, pcc), op, fp, alpha, ret);
+        SUB_END(28);
         const double r0 = uniform(ret[0 * 64]), r1 = uniform(ret[1 * 64]), r2 = uniform(ret[2 * 64]),
                      r3 = uniform(ret[3 * 64]), r4 = uniform(ret[4 * 64]);
         // (the second sweep L of a real-time iteration only applies the step and reports the objective:
@@ -2973,7 +2977,6 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     auto single_qp = [&](int p) {
         SUB_BEGIN();
         coop_sync();
-        SUB_END(28);
         Lane C;
         PC<NH> pcc;
         problem_of_lane<NH>(L, pc, (ldouble *)pc_lds, p, C, pcc);
@@ -2985,9 +2988,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         const int mt = __builtin_amdgcn_readlane(m_total, p);
         int qit = __builtin_amdgcn_readlane(qp_it, p);
         int n_state = LS_QP, n_status = -1, add_total = 0, add_sqp = 0;
-        SUB_END(29);
         coop_B0<NH>(C, pcc, op, s, mt, ret);
-        SUB_END(30);
+        SUB_END(31);
         STAMP(12, true);
         const double Rg = uniform(ret[0 * 64]), Rb = uniform(ret[1 * 64]), Rd = uniform(ret[2 * 64]),
                      Rm = uniform(ret[3 * 64]), mu = uniform(ret[4 * 64]);
@@ -3098,22 +3100,32 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
         Lane R = C;
         R.region = region_bytes(L);
         R.lane = ((unsigned)(N + 1) + (unsigned)slot * nblk) * rec_bytes;
+        SUB_BEGIN();
         coop_sync();
         for (int k0 = 0; k0 <= N; k0 += 64) {
             const int kj = k0 + (int)threadIdx.x;
             if (kj > N) continue;
             const Lane S = stage_lane(C, (unsigned)kj), D = stage_lane(R, (unsigned)kj);
-            for (int f0 = 0; f0 < M::F; f0 += 16) {
-                double tmp[16];
+            // what is alive between two interior-point iterations: the linearisation, the iterate and the
+            // pending step (fields X .. TU and DV .. the end); residuals, factors and right-hand sides are
+            // formed anew by the next iteration's first sweep before anything reads them.  In the
+            // [stage][field][lane] layout every word of a problem sits in a cache line of its own, so a
+            // word not copied is a line not fetched.
+            for (int part = 0; part < 2; ++part) {
+                const int lo = part ? M::DV : M::X, hi = part ? M::F : M::TU + M::R;
+                for (int f0 = lo; f0 < hi; f0 += 16) {
+                    double tmp[16];
 #pragma unroll
-                for (int f = 0; f < 16; ++f) tmp[f] = (f0 + f < M::F) ? ldw<ANY>(S, 0, f0 + f) : 0.0;
+                    for (int f = 0; f < 16; ++f) tmp[f] = (f0 + f < hi) ? ldw<ANY>(S, 0, f0 + f) : 0.0;
 #pragma unroll
-                for (int f = 0; f < 16; ++f)
-                    if (f0 + f < M::F) stw<ANY>(D, 0, f0 + f, tmp[f]);
+                    for (int f = 0; f < 16; ++f)
+                        if (f0 + f < hi) stw<ANY>(D, 0, f0 + f, tmp[f]);
+                }
             }
         }
         if ((int)threadIdx.x == p) { L.roff = R.lane; solo = true; }
         coop_sync();
+        SUB_END(29);
         return true;
     };
     for (;;) {

@@ -50,8 +50,8 @@ cyc[:, mark_slots] = 0
 # parts of the single-problem sweeps (already contained in slots 12..15)
 # bursts (N < 64): slot 12 holds whole bursts, lanes-sum / 64 = iterations + QP ends
 sub_slots = {16: "    burst: B0 rows + reductions", 17: "    burst: Riccati pipeline", 24: "    burst: F affine", 25: "    burst: Bs", 26: "    burst: F both",
-             27: "    burst: loads at the start", 28: "    fence before B0", 29: "    problem parameters",
-             30: "    B0 call"}
+             27: "    burst: loads at the start / step selection", 28: "    sweep L, single-problem form",
+             29: "    move to a region", 30: "    burst: stores at the end", 31: "    separate sweeps: B0"}
 sub_raw = {k: cyc[used, k].sum() for k in sub_slots}
 cyc[:, list(sub_slots)] = 0
 tot = cyc[used].sum()
