@@ -91,21 +91,18 @@ struct Map {
     static constexpr int PRB = RB + 5;         // 5  P(k+1) * rb
     static constexpr int K = PRB + 5;          // 10 feedback gain, row-major [2][5]
     static constexpr int LDL = K + 10;         // 3  l10, 1/d0, 1/d1 of the LDL' of M_uu
-    static constexpr int P = LDL + 3;          // 15 cost-to-go Hessian, lower triangle
-    static constexpr int KV = P + 15;          // 2  feed-forward
-    static constexpr int PV = KV + 2;          // 5  cost-to-go gradient
-    static constexpr int DV = PV + 5;          // 7  step
-    static constexpr int DPI = DV + 7;         // 5
-    static constexpr int DVA = DPI + 5;        // 7  affine (predictor) step
+    static constexpr int KV = LDL + 3;         // 2  feed-forward
+    static constexpr int DV = KV + 2;          // 7  step
+    static constexpr int DVA = DV + 7;         // 7  affine (predictor) step
     // the centring-only solution, computed alongside the corrector one; same order and
-    // distance as KV..DPI so that "solution 2" is "solution 1" + SOL2
+    // distance as KV, DV so that "solution 2" is "solution 1" + SOL2
     static constexpr int KV2 = DVA + 7;        // 2
-    static constexpr int PV2 = KV2 + 2;        // 5
-    static constexpr int DV2 = PV2 + 5;        // 7
-    static constexpr int DPI2 = DV2 + 7;       // 5
+    static constexpr int DV2 = KV2 + 2;        // 7
     static constexpr int SOL2 = KV2 - KV;
-    static constexpr int F = DPI2 + 5;
-    static_assert(PV2 - PV == SOL2 && DV2 - DV == SOL2 && DPI2 - DPI == SOL2, "solution 2 layout");
+    static constexpr int F = DV2 + 7;
+    // (The cost-to-go Hessian and gradient never reach the workspace: the step of the dynamics
+    // multipliers is formed by the next backward sweep from the stationarity of the Newton system.)
+    static_assert(DV2 - DV == SOL2, "solution 2 layout");
 };
 
 // A = dPhi/dx and B = dPhi/du of one RK4 step have this pattern (h* = 6*(h/6)):
@@ -1088,14 +1085,15 @@ struct B0Out {
 template <int NH>
 struct B0In {
     double x[NX], u[NU], v[NZ], vo[NZ], dv[NZ], dva[NZ], qpi[NX];
+    double rgo[NX];      // x-part of the stationarity residual the iteration before left behind
     double ll[Map<NH>::R], lu[Map<NH>::R], tl[Map<NH>::R], tu[Map<NH>::R], til_[Map<NH>::R], tiu_[Map<NH>::R];
     AB ab;
     double bv[NX];
 };
 
-// first half: all loads of the stage (dpi: step of the dynamics multiplier, used by the apply part only)
+// first half: all loads of the stage
 template <int NH, int KIND>
-DEV void stage_B0_load(const Lane &L, int k, const Step &sp, B0In<NH> &in, double *dpi, const KR &kr = KR{false, false})
+DEV void stage_B0_load(const Lane &L, int k, const Step &sp, B0In<NH> &in, const KR &kr = KR{false, false})
 {
     typedef Map<NH> M;
     // ---- loads ----
@@ -1114,7 +1112,7 @@ DEV void stage_B0_load(const Lane &L, int k, const Step &sp, B0In<NH> &in, doubl
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         qpi[i] = (KIND != FIRST) ? ldw<KIND>(L, k, M::QPI + i) : 0.0;
-        dpi[i] = (KIND != FIRST) ? ldw_lane<KIND>(L, k, M::DPI + i, sol) : 0.0;
+        in.rgo[i] = (KIND != FIRST) ? ldw<KIND>(L, k, M::RG + NU + i) : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
@@ -1142,13 +1140,13 @@ DEV void stage_B0_load(const Lane &L, int k, const Step &sp, B0In<NH> &in, doubl
     __builtin_amdgcn_sched_barrier(0);     // every load of the stage is in flight before the first use
 }
 
-// the pending step on the primal and the dynamics multiplier.  ST = false: nothing is stored, the
-// caller keeps the stage in registers (in.v, in.qpi are the updated values either way)
+// the pending step on the primal.  ST = false: nothing is stored, the caller keeps the stage in
+// registers (in.v is the updated value either way)
 template <int NH, int KIND, bool ST = true>
-DEV void stage_B0_apply(const Lane &L, int k, const Step &sp, B0In<NH> &in, const double *dpi, const KR &kr = KR{false, false})
+DEV void stage_B0_apply(const Lane &L, int k, const Step &sp, B0In<NH> &in, const KR &kr = KR{false, false})
 {
     typedef Map<NH> M;
-    double (&v)[NZ] = in.v, (&vo)[NZ] = in.vo, (&dv)[NZ] = in.dv, (&qpi)[NX] = in.qpi;
+    double (&v)[NZ] = in.v, (&vo)[NZ] = in.vo, (&dv)[NZ] = in.dv;
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
         v[j] = vo[j];
@@ -1157,28 +1155,115 @@ DEV void stage_B0_apply(const Lane &L, int k, const Step &sp, B0In<NH> &in, cons
             if (ST) stw<KIND>(L, k, M::V + j, v[j]);
         }
     }
+}
+
+// The pending step on the stage's multipliers and slacks, and the stage's own part of the step of its
+// dynamics multiplier.  That step solves the x_k block of the Newton system,
+//   Ht_xx dx_k + A_k' dpi_(k+1) - dpi_k = -gt_x,
+// backwards from the last stage (dpi_chain below), gt and Ht being the right-hand side and the barrier
+// Hessian of the system that produced the step; both are formed again here from the iterate before the
+// step and the stationarity residual it left (in.rgo), so neither the cost-to-go Hessian nor its
+// gradient has to be kept.  cx = gt_x + Ht_xx dx_k.
+// RC = true (stage resident in registers): in.til_ / in.tiu_ hold the reciprocals of the slacks.
+template <int NH, int KIND, bool ST = true, bool RC = false>
+DEV void stage_B0_step_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, const Step &sp, B0In<NH> &in,
+                            double *cx, const KR &kr = KR{false, false})
+{
+    typedef Map<NH> M;
+    double (&x)[NX] = in.x, (&u)[NU] = in.u, (&vo)[NZ] = in.vo, (&dv)[NZ] = in.dv, (&dva)[NZ] = in.dva;
+    double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
+           (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
+    double g[NZ], Hd[NZ], gto[NX], Hto[NX], oxx = 0.0, oxy = 0.0, oyy = 0.0;
+    cost_terms<NH, KIND>(L, o, pc, kr, x, u, g, Hd);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { gto[i] = in.rgo[i]; Hto[i] = Hd[NU + i]; }
+#pragma unroll
+    for (int r = 0; r < M::R; ++r) {
+        if (!row_present<KIND>(r)) continue;
+        const bool pr = row_on<KIND>(kr, r) && ((r < 9) || (r - 9 < L.nobs));
+        double c, jx, jy, lo, up;
+        row_geom<NH>(pc, r, x, u, c, jx, jy);
+        row_bounds<NH, KIND>(L, pc, kr, r, lo, up);
+        const double dlo = lo - c, dup = up - c;
+        double l_l = ll[r], l_u = lu[r], t_l = tl[r], t_u = tu[r];
+        double jvo = jdot(r, jx, jy, vo);
+        double rdl = (dlo - jvo) + t_l;
+        double rdu = (jvo - dup) + t_u;
+        double til = (MPCX_STORE_RECIP || RC) ? til_[r] : 1.0 / t_l, tiu = (MPCX_STORE_RECIP || RC) ? tiu_[r] : 1.0 / t_u;
+        double jda = jdot(r, jx, jy, dva);
+        double rml, rmu;
+        row_rm(sp.mode, sp.sigma_mu, jda, l_l, l_u, t_l, t_u, til, tiu, rdl, rdu, rml, rmu);
+        if (r >= NU && KIND != FIRST) {
+            // this row in the right-hand side and the barrier Hessian of the system solved
+            const double qo = fma(-l_l, rdl, rml) * til - fma(-l_u, rdu, rmu) * tiu;
+            const double wo = l_l * til + l_u * tiu;
+            if (r < ROW_G0) {
+                gto[r - NU] = pr ? gto[r - NU] + qo : gto[r - NU];
+                Hto[r - NU] = pr ? Hto[r - NU] + wo : Hto[r - NU];
+            } else {
+                gto[0] = pr ? fma(jx, qo, gto[0]) : gto[0];
+                gto[1] = pr ? fma(jy, qo, gto[1]) : gto[1];
+                const double wx = wo * jx, wy = wo * jy;
+                oxx = pr ? fma(wx, jx, oxx) : oxx;
+                oxy = pr ? fma(wy, jx, oxy) : oxy;
+                oyy = pr ? fma(wy, jy, oyy) : oyy;
+            }
+        }
+        double jd = jdot(r, jx, jy, dv);
+        double dtl = jd - rdl;
+        double dtu = -jd - rdu;
+        double dll = -(fma(l_l, dtl, rml) * til);
+        double dlu = -(fma(l_u, dtu, rmu) * tiu);
+        double t;
+        t = fma(sp.alpha, dll, l_l); t = (t < o.lam_min) ? o.lam_min : t; l_l = sp.have ? t : l_l;
+        t = fma(sp.alpha, dlu, l_u); t = (t < o.lam_min) ? o.lam_min : t; l_u = sp.have ? t : l_u;
+        t = fma(sp.alpha, dtl, t_l); t = (t < o.t_min) ? o.t_min : t; t_l = sp.have ? t : t_l;
+        t = fma(sp.alpha, dtu, t_u); t = (t < o.t_min) ? o.t_min : t; t_u = sp.have ? t : t_u;
+        if (ST) {
+            stw<KIND>(L, k, M::LAML + r, l_l);
+            stw<KIND>(L, k, M::LAMU + r, l_u);
+            stw<KIND>(L, k, M::TL + r, t_l);
+            stw<KIND>(L, k, M::TU + r, t_u);
+        }
+        ll[r] = l_l; lu[r] = l_u; tl[r] = t_l; tu[r] = t_u;      // (in.* hold the updated values on return)
+    }
+    const double *dx = &dv[NU];
+    cx[0] = fma(oxy, dx[1], fma(Hto[0] + oxx, dx[0], gto[0]));
+    cx[1] = fma(Hto[1] + oyy, dx[1], fma(oxy, dx[0], gto[1]));
+#pragma unroll
+    for (int i = 2; i < NX; ++i) cx[i] = fma(Hto[i], dx[i], gto[i]);
+}
+
+// d = cx + A_k' dpn: the step of the dynamics multiplier of stage k from that of stage k+1
+DEV void dpi_chain(const AB &ab, const double *cx, const double *dpn, double *d)
+{
+    d[0] = cx[0] + dpn[0];
+    d[1] = cx[1] + dpn[1];
+    d[2] = fma(ab.a12, dpn[1], fma(ab.a02, dpn[0], cx[2])) + dpn[2];
+    d[3] = fma(ab.a23, dpn[2], fma(ab.a13, dpn[1], fma(ab.a03, dpn[0], cx[3]))) + dpn[3];
+    d[4] = fma(ab.a24, dpn[2], fma(ab.a14, dpn[1], fma(ab.a04, dpn[0], cx[4]))) + dpn[4];
+}
+
+// the pending step on the dynamics multiplier, d = its step (in.qpi is the updated value)
+template <int NH, int KIND, bool ST = true>
+DEV void stage_B0_apply_pi(const Lane &L, int k, const Step &sp, B0In<NH> &in, const double *d, const KR &kr = KR{false, false})
+{
+    typedef Map<NH> M;
+    double (&qpi)[NX] = in.qpi;
     if (KIND != FIRST) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            qpi[i] = sp.have ? fma(sp.alpha, dpi[i], qpi[i]) : qpi[i];
+            qpi[i] = sp.have ? fma(sp.alpha, d[i], qpi[i]) : qpi[i];
             qpi[i] = is_first<KIND>(kr) ? 0.0 : qpi[i];
             if (ST) stw<KIND>(L, k, M::QPI + i, qpi[i]);
         }
     }
 }
 
-template <int NH, int KIND>
-DEV void stage_B0_head(const Lane &L, int k, const Step &sp, B0In<NH> &in, const KR &kr = KR{false, false})
-{
-    double dpi[NX];
-    stage_B0_load<NH, KIND>(L, k, sp, in, dpi, kr);
-    stage_B0_apply<NH, KIND>(L, k, sp, in, dpi, kr);
-}
-
-// second half: rows, residuals, barrier Hessian, affine right-hand side.  vxn / qpin: updated
-// x-part of v and dynamics multiplier of stage k+1.
+// second half (the pending step has been applied to the whole stage): rows, residuals, barrier Hessian,
+// affine right-hand side.  vxn / qpin: updated x-part of v and dynamics multiplier of stage k+1.
 // RC = true (stage resident in registers): in.til_ / in.tiu_ carry the reciprocals of the slacks from
-// sweep to sweep; they hold those of the slacks on entry and of the updated slacks on return
+// sweep to sweep; on return they hold those of the updated slacks
 template <int NH, int KIND, bool ST = true, bool RC = false>
 DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, const Step &sp, B0In<NH> &in,
                        const double *vxn, const double *qpin, B0Out &out, const KR &kr = KR{false, false})
@@ -1186,8 +1271,7 @@ DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
     typedef Map<NH> M;
     out.ng = out.nb = out.nd = out.nm = 0.0;
     double ssum = 0.0;
-    double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&vo)[NZ] = in.vo, (&dv)[NZ] = in.dv,
-           (&dva)[NZ] = in.dva, (&qpi)[NX] = in.qpi;
+    double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&qpi)[NX] = in.qpi;
     double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
            (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
     AB &ab = in.ab;
@@ -1219,34 +1303,7 @@ DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
         row_geom<NH>(pc, r, x, u, c, jx, jy);
         row_bounds<NH, KIND>(L, pc, kr, r, lo, up);
         const double dlo = lo - c, dup = up - c;
-        double l_l = ll[r], l_u = lu[r], t_l = tl[r], t_u = tu[r];
-        {
-            // pending step on this row's multipliers and slacks
-            double jvo = jdot(r, jx, jy, vo);
-            double rdl = (dlo - jvo) + t_l;
-            double rdu = (jvo - dup) + t_u;
-            double til = (MPCX_STORE_RECIP || RC) ? til_[r] : 1.0 / t_l, tiu = (MPCX_STORE_RECIP || RC) ? tiu_[r] : 1.0 / t_u;
-            double jda = jdot(r, jx, jy, dva);
-            double rml, rmu;
-            row_rm(sp.mode, sp.sigma_mu, jda, l_l, l_u, t_l, t_u, til, tiu, rdl, rdu, rml, rmu);
-            double jd = jdot(r, jx, jy, dv);
-            double dtl = jd - rdl;
-            double dtu = -jd - rdu;
-            double dll = -(fma(l_l, dtl, rml) * til);
-            double dlu = -(fma(l_u, dtu, rmu) * tiu);
-            double t;
-            t = fma(sp.alpha, dll, l_l); t = (t < o.lam_min) ? o.lam_min : t; l_l = sp.have ? t : l_l;
-            t = fma(sp.alpha, dlu, l_u); t = (t < o.lam_min) ? o.lam_min : t; l_u = sp.have ? t : l_u;
-            t = fma(sp.alpha, dtl, t_l); t = (t < o.t_min) ? o.t_min : t; t_l = sp.have ? t : t_l;
-            t = fma(sp.alpha, dtu, t_u); t = (t < o.t_min) ? o.t_min : t; t_u = sp.have ? t : t_u;
-            if (ST) {
-                stw<KIND>(L, k, M::LAML + r, l_l);
-                stw<KIND>(L, k, M::LAMU + r, l_u);
-                stw<KIND>(L, k, M::TL + r, t_l);
-                stw<KIND>(L, k, M::TU + r, t_u);
-            }
-            ll[r] = l_l; lu[r] = l_u; tl[r] = t_l; tu[r] = t_u;      // (in.* hold the updated values on return)
-        }
+        const double l_l = ll[r], l_u = lu[r], t_l = tl[r], t_u = tu[r];      // (after the pending step)
         double jv = jdot(r, jx, jy, v);
         double dlm = l_u - l_l;
         if (r < ROW_G0) rg[r] = pr ? rg[r] + dlm : rg[r];
@@ -1322,13 +1379,29 @@ DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
 }
 
 // B0, row part of stage k: applies the pending step to the stage's iterate, then residuals,
-// barrier Hessian and affine right-hand side
+// barrier Hessian and affine right-hand side.  dpn: step of the dynamics multiplier of stage k+1 on
+// entry, of stage k on return.
 template <int NH, int KIND>
 DEV void stage_B0_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, const Step &sp,
-                       const double *vxn, const double *qpin, B0Out &out)
+                       const double *vxn, const double *qpin, double *dpn, B0Out &out)
 {
     B0In<NH> in;
-    stage_B0_head<NH, KIND>(L, k, sp, in);
+    stage_B0_load<NH, KIND>(L, k, sp, in);
+    stage_B0_apply<NH, KIND>(L, k, sp, in);
+    double cx[NX];
+    stage_B0_step_rows<NH, KIND>(L, o, pc, k, sp, in, cx);
+    if (KIND != FIRST) {
+        double d[NX];
+        if (KIND == LAST) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) d[i] = cx[i];
+        } else {
+            dpi_chain(in.ab, cx, dpn, d);
+        }
+        stage_B0_apply_pi<NH, KIND>(L, k, sp, in, d);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dpn[i] = d[i];
+    }
     stage_B0_tail<NH, KIND>(L, o, pc, k, sp, in, vxn, qpin, out);
 }
 
@@ -1348,9 +1421,25 @@ DEV void feed_forward(double l10, double d0, double d1, double m0, double m1, do
     kv[1] = -z1;
 }
 
+// prb = P(k+1) rb of a stage
+DEV void ric_prb(const B0Out &in, const double *Pn, double *prb)
+{
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        double acc = psym(Pn, i, 0) * in.rb[0];
+#pragma unroll
+        for (int j = 1; j < NX; ++j) acc = fma(psym(Pn, i, j), in.rb[j], acc);
+        prb[i] = acc;
+    }
+}
+
 // FF = false: kv receives (m0, m1) instead of the feed-forward, which the caller forms with
-// feed_forward() when it needs it (the lane pipelines need it once, after their last step)
-template <int KIND, bool FF = true>
+// feed_forward() when it needs it (the lane pipelines need it once, after their last step).
+// PART = 0: the whole stage.  The two recursions of a stage do not depend on each other's results of
+// the same step, so a lane pipeline may run them one after the other: PART = 1 is the factorisation alone
+// (K, the pivots, P(k) from P(k+1)), PART = 2 the backward substitution alone (p(k) and the input part of
+// the right-hand side from p(k+1), with ro.prb = P(k+1) rb and ro.K already in place).
+template <int KIND, bool FF = true, int PART = 0>
 DEV void stage_B0_ric(const Lane &L, const B0Out &in, const double *Pn, const double *pn, double *Po, double *po,
                       RicOut &ro)
 {
@@ -1370,88 +1459,92 @@ DEV void stage_B0_ric(const Lane &L, const B0Out &in, const double *Pn, const do
     } else {
         // w = p(k+1) + P(k+1) rb
         double w[NX];
+        if (PART == 0) ric_prb(in, Pn, ro.prb);
+        if (PART != 1) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            double acc = psym(Pn, i, 0) * in.rb[0];
-#pragma unroll
-            for (int j = 1; j < NX; ++j) acc = fma(psym(Pn, i, j), in.rb[j], acc);
-            ro.prb[i] = acc;
-            w[i] = pn[i] + acc;
+            for (int i = 0; i < NX; ++i) w[i] = pn[i] + ro.prb[i];
         }
-        // PBA = P(k+1) [B A]; columns 0,1 = B, 2..6 = A
-        double PBA[NX][NZ];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const double p0 = psym(Pn, i, 0), p1 = psym(Pn, i, 1), p2 = psym(Pn, i, 2),
-                         p3 = psym(Pn, i, 3), p4 = psym(Pn, i, 4);
-            PBA[i][0] = fma(p3, L.hB, fma(p2, in.ab.b20, fma(p1, in.ab.b10, p0 * in.ab.b00)));
-            PBA[i][1] = fma(p4, L.hB, fma(p2, in.ab.b21, fma(p1, in.ab.b11, p0 * in.ab.b01)));
-            PBA[i][2] = p0;
-            PBA[i][3] = p1;
-            PBA[i][4] = fma(p1, in.ab.a12, p0 * in.ab.a02) + p2;
-            PBA[i][5] = fma(p2, in.ab.a23, fma(p1, in.ab.a13, p0 * in.ab.a03)) + p3;
-            PBA[i][6] = fma(p2, in.ab.a24, fma(p1, in.ab.a14, p0 * in.ab.a04)) + p4;
-        }
-        // M = Ht + [B A]' PBA, lower triangle
-        double Mm[NZ][NZ];
-#pragma unroll
-        for (int c = 0; c < NZ; ++c) {
-#pragma unroll
-            for (int r = c; r < NZ; ++r) {
-                double acc = 0.0;
-                if (r == c) acc = (r == 2) ? in.Ht[2] + in.hxx : (r == 3) ? in.Ht[3] + in.hyy : in.Ht[r];
-                else if (r == 3 && c == 2) acc = in.hxy;
-                if (r == 0)
-                    acc = fma(L.hB, PBA[3][c], fma(in.ab.b20, PBA[2][c], fma(in.ab.b10, PBA[1][c], fma(in.ab.b00, PBA[0][c], acc))));
-                else if (r == 1)
-                    acc = fma(L.hB, PBA[4][c], fma(in.ab.b21, PBA[2][c], fma(in.ab.b11, PBA[1][c], fma(in.ab.b01, PBA[0][c], acc))));
-                else if (r == 2) acc = acc + PBA[0][c];
-                else if (r == 3) acc = acc + PBA[1][c];
-                else if (r == 4) acc = fma(in.ab.a12, PBA[1][c], fma(in.ab.a02, PBA[0][c], acc)) + PBA[2][c];
-                else if (r == 5) acc = fma(in.ab.a23, PBA[2][c], fma(in.ab.a13, PBA[1][c], fma(in.ab.a03, PBA[0][c], acc))) + PBA[3][c];
-                else acc = fma(in.ab.a24, PBA[2][c], fma(in.ab.a14, PBA[1][c], fma(in.ab.a04, PBA[0][c], acc))) + PBA[4][c];
-                Mm[r][c] = acc;
-            }
-        }
-        const double d0 = 1.0 / Mm[0][0];                          // reciprocal pivots
-        const double l10 = Mm[1][0] * d0;
-        const double d1 = 1.0 / fma(-l10, Mm[1][0], Mm[1][1]);
-        ro.l10 = l10; ro.d0 = d0; ro.d1 = d1;
         double Kg[NU][NX];
+        if (PART != 2) {
+            // PBA = P(k+1) [B A]; columns 0,1 = B, 2..6 = A
+            double PBA[NX][NZ];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            double y0 = Mm[NU + i][0];
-            double y1 = fma(-l10, y0, Mm[NU + i][1]);
-            double z0 = y0 * d0, z1 = y1 * d1;
-            double s0 = fma(-l10, z1, z0);
-            Kg[0][i] = -s0;
-            Kg[1][i] = -z1;
-            ro.K[0][i] = Kg[0][i];
-            ro.K[1][i] = Kg[1][i];
-        }
-        // right-hand side of this stage and feed-forward
-        double m[NZ];
-#pragma unroll
-        for (int j = 0; j < NZ; ++j) m[j] = in.gt[j];
-        add_BAt(L, in.ab, w, m);
-        if (FF) feed_forward(l10, d0, d1, m[0], m[1], ro.kv);
-        else { ro.kv[0] = m[0]; ro.kv[1] = m[1]; }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) po[i] = fma(Kg[1][i], m[1], fma(Kg[0][i], m[0], m[NU + i]));
-        // P(k) = M_xx + M_xu K
-#pragma unroll
-        for (int i = 0; i < NX; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                double e = fma(Mm[NU + i][0], Kg[0][j], Mm[NU + i][NU + j]);
-                Po[tri(i, j)] = fma(Mm[NU + i][1], Kg[1][j], e);
+            for (int i = 0; i < NX; ++i) {
+                const double p0 = psym(Pn, i, 0), p1 = psym(Pn, i, 1), p2 = psym(Pn, i, 2),
+                             p3 = psym(Pn, i, 3), p4 = psym(Pn, i, 4);
+                PBA[i][0] = fma(p3, L.hB, fma(p2, in.ab.b20, fma(p1, in.ab.b10, p0 * in.ab.b00)));
+                PBA[i][1] = fma(p4, L.hB, fma(p2, in.ab.b21, fma(p1, in.ab.b11, p0 * in.ab.b01)));
+                PBA[i][2] = p0;
+                PBA[i][3] = p1;
+                PBA[i][4] = fma(p1, in.ab.a12, p0 * in.ab.a02) + p2;
+                PBA[i][5] = fma(p2, in.ab.a23, fma(p1, in.ab.a13, p0 * in.ab.a03)) + p3;
+                PBA[i][6] = fma(p2, in.ab.a24, fma(p1, in.ab.a14, p0 * in.ab.a04)) + p4;
             }
+            // M = Ht + [B A]' PBA, lower triangle
+            double Mm[NZ][NZ];
+#pragma unroll
+            for (int c = 0; c < NZ; ++c) {
+#pragma unroll
+                for (int r = c; r < NZ; ++r) {
+                    double acc = 0.0;
+                    if (r == c) acc = (r == 2) ? in.Ht[2] + in.hxx : (r == 3) ? in.Ht[3] + in.hyy : in.Ht[r];
+                    else if (r == 3 && c == 2) acc = in.hxy;
+                    if (r == 0)
+                        acc = fma(L.hB, PBA[3][c], fma(in.ab.b20, PBA[2][c], fma(in.ab.b10, PBA[1][c], fma(in.ab.b00, PBA[0][c], acc))));
+                    else if (r == 1)
+                        acc = fma(L.hB, PBA[4][c], fma(in.ab.b21, PBA[2][c], fma(in.ab.b11, PBA[1][c], fma(in.ab.b01, PBA[0][c], acc))));
+                    else if (r == 2) acc = acc + PBA[0][c];
+                    else if (r == 3) acc = acc + PBA[1][c];
+                    else if (r == 4) acc = fma(in.ab.a12, PBA[1][c], fma(in.ab.a02, PBA[0][c], acc)) + PBA[2][c];
+                    else if (r == 5) acc = fma(in.ab.a23, PBA[2][c], fma(in.ab.a13, PBA[1][c], fma(in.ab.a03, PBA[0][c], acc))) + PBA[3][c];
+                    else acc = fma(in.ab.a24, PBA[2][c], fma(in.ab.a14, PBA[1][c], fma(in.ab.a04, PBA[0][c], acc))) + PBA[4][c];
+                    Mm[r][c] = acc;
+                }
+            }
+            const double d0 = 1.0 / Mm[0][0];                          // reciprocal pivots
+            const double l10 = Mm[1][0] * d0;
+            const double d1 = 1.0 / fma(-l10, Mm[1][0], Mm[1][1]);
+            ro.l10 = l10; ro.d0 = d0; ro.d1 = d1;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double y0 = Mm[NU + i][0];
+                double y1 = fma(-l10, y0, Mm[NU + i][1]);
+                double z0 = y0 * d0, z1 = y1 * d1;
+                double s0 = fma(-l10, z1, z0);
+                Kg[0][i] = -s0;
+                Kg[1][i] = -z1;
+                ro.K[0][i] = Kg[0][i];
+                ro.K[1][i] = Kg[1][i];
+            }
+            // P(k) = M_xx + M_xu K
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    double e = fma(Mm[NU + i][0], Kg[0][j], Mm[NU + i][NU + j]);
+                    Po[tri(i, j)] = fma(Mm[NU + i][1], Kg[1][j], e);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { Kg[0][i] = ro.K[0][i]; Kg[1][i] = ro.K[1][i]; }
+        }
+        if (PART != 1) {
+            // right-hand side of this stage and feed-forward
+            double m[NZ];
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) m[j] = in.gt[j];
+            add_BAt(L, in.ab, w, m);
+            if (FF) feed_forward(ro.l10, ro.d0, ro.d1, m[0], m[1], ro.kv);
+            else { ro.kv[0] = m[0]; ro.kv[1] = m[1]; }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) po[i] = fma(Kg[1][i], m[1], fma(Kg[0][i], m[0], m[NU + i]));
+        }
     }
 }
 
-// the factors of stage k and its cost-to-go Hessian go to the workspace
+// the factors of stage k go to the workspace
 template <int NH, int KIND>
-DEV void store_ric(const Lane &L, int k, bool factors, bool hessian, const RicOut &ro, const double *Pn)
+DEV void store_ric(const Lane &L, int k, bool factors, const RicOut &ro)
 {
     typedef Map<NH> M;
     if (factors) {
@@ -1467,10 +1560,6 @@ DEV void store_ric(const Lane &L, int k, bool factors, bool hessian, const RicOu
         stw<KIND>(L, k, M::KV + 0, ro.kv[0]);
         stw<KIND>(L, k, M::KV + 1, ro.kv[1]);
     }
-    if (hessian) {
-#pragma unroll
-        for (int i = 0; i < 15; ++i) stw<KIND>(L, k, M::P + i, Pn[i]);
-    }
 }
 
 template <int NH>
@@ -1482,19 +1571,19 @@ __device__ __attribute__((noinline)) void sweep_B0(Lane L, PC<NH> pc, const mpcx
     Step sp;
     sp.have = sp_have; sp.mode = sp_mode; sp.sigma_mu = sp_sigma_mu; sp.alpha = sp_alpha;
     const int N = L.N;
-    double Pn[15], pn[NX], vxn[NX], qpin[NX];
+    double Pn[15], pn[NX], vxn[NX], qpin[NX], dpn[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { pn[i] = 0.0; vxn[i] = 0.0; qpin[i] = 0.0; }
+    for (int i = 0; i < NX; ++i) { pn[i] = 0.0; vxn[i] = 0.0; qpin[i] = 0.0; dpn[i] = 0.0; }
 #pragma unroll
     for (int i = 0; i < 15; ++i) Pn[i] = 0.0;
     double ng = 0.0, nb = 0.0, nd = 0.0, nm = 0.0, sum = 0.0;
 #define B0_STAGE(KIND, kk)                                                             \
     {                                                                                  \
         B0Out t;                                                                       \
-        stage_B0_rows<NH, KIND>(L, o, pc, kk, sp, vxn, qpin, t);                       \
+        stage_B0_rows<NH, KIND>(L, o, pc, kk, sp, vxn, qpin, dpn, t);                  \
         RicOut ro;                                                                     \
         stage_B0_ric<KIND>(L, t, Pn, pn, Pn, pn, ro);                                  \
-        store_ric<NH, KIND>(L, kk, KIND != LAST, KIND != FIRST, ro, Pn);                     \
+        store_ric<NH, KIND>(L, kk, KIND != LAST, ro);                                  \
         ng = dmax(ng, t.ng); nb = dmax(nb, t.nb); nd = dmax(nd, t.nd); nm = dmax(nm, t.nm); \
         sum = sum + t.ssum;                                                            \
         _Pragma("unroll") for (int i = 0; i < NX; ++i) { vxn[i] = t.vx[i]; qpin[i] = t.qpi[i]; } \
@@ -1654,16 +1743,12 @@ DEV void stage_Bs_rec(const Lane &L, const BsOut &in, const double *pi1, const d
 }
 
 template <int NH, int KIND>
-DEV void store_rec(const Lane &L, int k, bool ff, bool grad, const double (*kvo)[NU], const double *pn1, const double *pn2)
+DEV void store_rec(const Lane &L, int k, bool ff, const double (*kvo)[NU])
 {
     typedef Map<NH> M;
     if (ff) {
         stw<KIND>(L, k, M::KV + 0, kvo[0][0]);  stw<KIND>(L, k, M::KV + 1, kvo[0][1]);
         stw<KIND>(L, k, M::KV2 + 0, kvo[1][0]); stw<KIND>(L, k, M::KV2 + 1, kvo[1][1]);
-    }
-    if (grad) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { stw<KIND>(L, k, M::PV + i, pn1[i]); stw<KIND>(L, k, M::PV2 + i, pn2[i]); }
     }
 }
 
@@ -1675,7 +1760,7 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, do
     stage_Bs_rows<NH, KIND>(L, o, pc, k, sigma_mu, t);
     double kvo[2][NU];
     stage_Bs_rec<KIND>(L, t, pn1, pn2, pn1, pn2, kvo);
-    store_rec<NH, KIND>(L, k, KIND != LAST, KIND != FIRST, kvo, pn1, pn2);
+    store_rec<NH, KIND>(L, k, KIND != LAST, kvo);
 }
 
 template <int NH>
@@ -1695,7 +1780,7 @@ __device__ __attribute__((noinline)) void sweep_Bs(Lane L, PC<NH> pc, const mpcx
 // ---------------------------------------------------------------------------
 // forward sweeps.  NS = 1: the affine (predictor) step: stores it (DVA), returns
 // its longest feasible length and the centring sums.  NS = 2: the corrector step
-// and the centring-only step side by side: stores both (DV, DPI and DV2, DPI2)
+// and the centring-only step side by side: stores both (DV and DV2)
 // and returns both lengths.
 // ---------------------------------------------------------------------------
 // the longest feasible step of a stage is num/den: the smallest ratio met in the stage, kept
@@ -1747,7 +1832,7 @@ struct FIn {
     double x[NX], u[NU], v[NZ], dva[NZ];
     double ll[Map<NH>::R], lu[Map<NH>::R], tl[Map<NH>::R], tu[Map<NH>::R], til_[Map<NH>::R], tiu_[Map<NH>::R];
     AB ab;
-    double rb[NX], kv[NS][NU], kg[NU][NX], pv[NS][NX], Pk[15];
+    double rb[NX], kv[NS][NU], kg[NU][NX];
 };
 
 template <int NH, int KIND, int NS>
@@ -1777,7 +1862,7 @@ DEV void stage_F_load(const Lane &L, int k, FIn<NH, NS> &in, const KR &kr = KR{f
         }
     }
     AB &ab = in.ab;
-    double (&rb)[NX] = in.rb, (&kv)[NS][NU] = in.kv, (&kg)[NU][NX] = in.kg, (&pv)[NS][NX] = in.pv, (&Pk)[15] = in.Pk;
+    double (&rb)[NX] = in.rb, (&kv)[NS][NU] = in.kv, (&kg)[NU][NX] = in.kg;
     ab = AB{};
 #pragma unroll
     for (int i = 0; i < NX; ++i) { rb[i] = 0.0; kg[0][i] = 0.0; kg[1][i] = 0.0; }
@@ -1797,47 +1882,27 @@ DEV void stage_F_load(const Lane &L, int k, FIn<NH, NS> &in, const KR &kr = KR{f
             kv[q][1] = ldw<KIND>(L, k, M::KV + q * M::SOL2 + 1);
         }
     }
-    if (NS == 2 && KIND != FIRST) {
-#pragma unroll
-        for (int q = 0; q < NS; ++q)
-#pragma unroll
-            for (int i = 0; i < NX; ++i) pv[q][i] = ldw<KIND>(L, k, M::PV + q * M::SOL2 + i);
-#pragma unroll
-        for (int i = 0; i < 15; ++i) Pk[i] = ldw<KIND>(L, k, M::P + i);
-    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// ST = false: nothing is stored; the steps of the stage come back in dvo[q][0..6] and (NS = 2) the
-// steps of the dynamics multiplier in dpo[q][0..4]
+// ST = false: nothing is stored; the steps of the stage come back in dvo[q][0..6]
 template <int NH, int KIND, int NS, bool ST = true, bool RC = false>
 DEV void stage_F_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu,
                          FIn<NH, NS> &in, double (*dx)[NX], FAcc &a, const KR &kr = KR{false, false},
-                         double (*dvo)[NZ] = nullptr, double (*dpo)[NX] = nullptr)
+                         double (*dvo)[NZ] = nullptr)
 {
     typedef Map<NH> M;
     double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&dva)[NZ] = in.dva;
     double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
            (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
     AB &ab = in.ab;
-    double (&rb)[NX] = in.rb, (&kv)[NS][NU] = in.kv, (&kg)[NU][NX] = in.kg, (&pv)[NS][NX] = in.pv, (&Pk)[15] = in.Pk;
+    double (&rb)[NX] = in.rb, (&kv)[NS][NU] = in.kv, (&kg)[NU][NX] = in.kg;
     double dvk[NS][NZ], dxn[NS][NX];
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) { dvk[q][NU + i] = dx[q][i]; dxn[q][i] = 0.0; }
         dvk[q][0] = dvk[q][1] = 0.0;
-        if (NS == 2 && KIND != FIRST) {
-            // multiplier step of the dynamics equation that defines x_k
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double acc = pv[q][i];
-#pragma unroll
-                for (int j = 0; j < NX; ++j) acc = fma(psym(Pk, i, j), dx[q][j], acc);
-                if (ST) stw<KIND>(L, k, M::DPI + q * M::SOL2 + i, acc);
-                else dpo[q][i] = acc;
-            }
-        }
         if (KIND != LAST) {
             F_rec(L, ab, kg, kv[q], rb, dx[q], dvk[q], dxn[q]);
             dvk[q][0] = is_last<KIND>(kr) ? 0.0 : dvk[q][0];
@@ -2169,7 +2234,7 @@ DEV double wave_min(double v)
 // LDS words of one wavefront behind the result slots of the sweeps: what a block of stages
 // hands to the next one (wave-uniform values, parked there so that they do not occupy
 // registers while the rows of the next block are computed)
-enum { CY_P = 0, CY_PV = 15, CY_VX = 20, CY_QPI = 25, CY_NORM = 30, CY_N = 35 };
+enum { CY_P = 0, CY_PV = 15, CY_VX = 20, CY_QPI = 25, CY_NORM = 30, CY_DPI = 35, CY_N = 40 };
 
 DEV void lds_order()
 {
@@ -2198,7 +2263,33 @@ __device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, const mpcx_
     const KR kr = {kj == 0, kj == N};
     B0In<NH> ld = {};
     SUB_BEGIN();
-    if (kj <= N) stage_B0_head<NH, ANY>(S, 0, sp, ld, kr);
+    double cx[NX], d[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { cx[i] = 0.0; d[i] = 0.0; }
+    if (kj <= N) {
+        stage_B0_load<NH, ANY>(S, 0, sp, ld, kr);
+        stage_B0_apply<NH, ANY>(S, 0, sp, ld, kr);
+        stage_B0_step_rows<NH, ANY>(S, o, pc, 0, sp, ld, cx, kr);
+    }
+    const int steps = (N - k0 < 64) ? N - k0 : 64;       // stages below N in this block
+    if (__builtin_amdgcn_readfirstlane((int)sp.have) != 0) {
+        // the step of the dynamics multipliers: a chain down the stages, run as a pipeline over the lanes
+        // (the lane of stage N starts it; the end lane takes what the block above handed down)
+        double dn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { dn[i] = carry[CY_DPI + i]; d[i] = (kj == N) ? cx[i] : 0.0; }
+        lds_order();
+        for (int s = 0; s < steps; ++s) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dn[i] = lane_above_keep<ONE>(dn[i], d[i]);
+            if (kj < N) dpi_chain(ld.ab, cx, dn, d);
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) carry[CY_DPI + i] = d[i];
+        }
+    }
+    if (kj <= N) stage_B0_apply_pi<NH, ANY>(S, 0, sp, ld, d, kr);
     double vxn[NX], qpin[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -2251,7 +2342,6 @@ __device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, const mpcx_
 #pragma unroll
     for (int i = 0; i < 15; ++i) Po[i] = 0.0;
     if (kj == N) stage_B0_ric<LAST>(S, t, Po, po, Po, po, ro);
-    const int steps = (N - k0 < 64) ? N - k0 : 64;       // stages below N in this block
     double Pi[15], pi[NX];
 #pragma unroll
     for (int i = 0; i < 15; ++i) Pi[i] = cP[i];
@@ -2273,7 +2363,7 @@ __device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, const mpcx_
         for (int i = 0; i < NX; ++i) carry[CY_PV + i] = po[i];
     }
     lds_order();
-    if (kj <= N) store_ric<NH, ANY>(S, 0, kj < N, kj > 0, ro, Po);
+    if (kj < N) store_ric<NH, ANY>(S, 0, true, ro);
     SUB_END(19);
 }
 
@@ -2340,7 +2430,7 @@ __device__ __attribute__((noinline)) void coop_Bs(COOP_PARAMS, const mpcx_opts *
 #pragma unroll
         for (int i = 0; i < NX; ++i) { c1[i] = bcast(o1[i], 0); c2[i] = bcast(o2[i], 0); }
         SUB_END(25);
-        if (kj <= N) store_rec<NH, ANY>(S, 0, kj < N, kj > 0, kvo, o1, o2);
+        if (kj < N) store_rec<NH, ANY>(S, 0, true, kvo);
     }
 }
 
@@ -2459,10 +2549,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
     sp.have = sp_have; sp.mode = sp_mode; sp.sigma_mu = sp_sigma_mu; sp.alpha = sp_alpha;
     // ---- this lane's stage ----
     B0In<NH> R = {};
-    double dpi[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) dpi[i] = 0.0;
-    if (on) stage_B0_load<NH, ANY>(S, 0, sp, R, dpi, kr);
+    if (on) stage_B0_load<NH, ANY>(S, 0, sp, R, kr);
     // the reciprocals of the slacks stay in registers with the stage (the sweeps recompute them where needed)
 #pragma unroll
     for (int r = 0; r < M::R; ++r) { R.til_[r] = 1.0 / R.tl[r]; R.tiu_[r] = 1.0 / R.tu[r]; }
@@ -2471,7 +2558,27 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
     SUB_END(27);
     for (;;) {
         // ================= B0: pending step, residuals, barrier Hessian, factorisation =================
-        if (on) stage_B0_apply<NH, ANY, false>(S, 0, sp, R, dpi, kr);
+        if (on) stage_B0_apply<NH, ANY, false>(S, 0, sp, R, kr);
+        {
+            double cx[NX], d[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { cx[i] = 0.0; d[i] = 0.0; }
+            if (on) stage_B0_step_rows<NH, ANY, false, true>(S, o, pc, 0, sp, R, cx, kr);
+            if (__builtin_amdgcn_readfirstlane((int)sp.have) != 0) {
+                // the step of the dynamics multipliers: a chain from stage N down, as a pipeline over the lanes
+                AB ac = R.ab;
+                fresh_ab(ac);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { cx[i] = fresh(cx[i]); d[i] = (kj == N) ? cx[i] : 0.0; }
+                for (int s = 0; s < N; ++s) {
+                    double dn[NX];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) dn[i] = lane_above<true>(d[i], 0.0);
+                    if (kj < N) dpi_chain(ac, cx, dn, d);
+                }
+            }
+            if (on) stage_B0_apply_pi<NH, ANY, false>(S, 0, sp, R, d, kr);
+        }
         double vxn[NX], qpin[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -2482,6 +2589,8 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
         if (on) stage_B0_tail<NH, ANY, false, true>(S, o, pc, 0, sp, R, vxn, qpin, t, kr);
 #pragma unroll
         for (int jj = 0; jj < NZ; ++jj) R.vo[jj] = R.v[jj];      // the iterate the next pending step starts from
+#pragma unroll
+        for (int i = 0; i < NX; ++i) R.rgo[i] = t.rg[NU + i];    // ... and the stationarity residual it leaves
         const int kend = N;
         const double Rg = uniform(wave_max(t.ng)), Rb = uniform(wave_max(t.nb)), Rd = uniform(wave_max(t.nd)),
                      Rm = uniform(wave_max(t.nm));
@@ -2511,14 +2620,34 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
         }
         // ================= Riccati factorisation and the affine backward substitution =================
         if (kj == N) stage_B0_ric<LAST>(S, t, Po, po, Po, po, ro);
+        // the factorisation down the lanes ...
         for (int s = 0; s < N; ++s) {
-            double Pi[15], pi[NX];
+            double Pi[15];
 #pragma unroll
             for (int i = 0; i < 15; ++i) Pi[i] = lane_above<true>(Po[i], 0.0);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) pi[i] = lane_above<true>(po[i], 0.0);
             sum = lane_above<true>(sum, 0.0) + t.ssum;
-            if (kj < N) stage_B0_ric<MID, false>(S, t, Pi, pi, Po, po, ro);
+            if (kj < N) stage_B0_ric<MID, false, 1>(S, t, Pi, nullptr, Po, nullptr, ro);
+        }
+        // ... then, with P(k+1) rb formed once from the final P(k+1), the affine right-hand side
+        {
+            double Pi[15];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) Pi[i] = lane_above<true>(Po[i], 0.0);
+            if (kj < N) ric_prb(t, Pi, ro.prb);
+            B0Out tp = t;
+            fresh_ab(tp.ab);
+#pragma unroll
+            for (int jj = 0; jj < NZ; ++jj) tp.gt[jj] = fresh(tp.gt[jj]);
+            RicOut rp = ro;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { rp.prb[i] = fresh(rp.prb[i]); rp.K[0][i] = fresh(rp.K[0][i]); rp.K[1][i] = fresh(rp.K[1][i]); }
+            for (int s = 0; s < N; ++s) {
+                double pi[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) pi[i] = lane_above<true>(po[i], 0.0);
+                if (kj < N) stage_B0_ric<MID, false, 2>(S, tp, nullptr, pi, nullptr, po, rp);
+            }
+            ro.kv[0] = rp.kv[0]; ro.kv[1] = rp.kv[1];
         }
         if (kj < N) feed_forward(ro.l10, ro.d0, ro.d1, ro.kv[0], ro.kv[1], ro.kv);
         const double mu = uniform(bcast(sum, 0) / (double)m_total);
@@ -2558,7 +2687,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             double dvo[1][NZ];
 #pragma unroll
             for (int jj = 0; jj < NZ; ++jj) dvo[0][jj] = 0.0;
-            if (on) stage_F_compute<NH, ANY, 1, false, true>(S, o, pc, 0, 0.0, ld, dxi, a, kr, dvo, nullptr);
+            if (on) stage_F_compute<NH, ANY, 1, false, true>(S, o, pc, 0, 0.0, ld, dxi, a, kr, dvo);
 #pragma unroll
             for (int jj = 0; jj < NZ; ++jj) R.dva[jj] = dvo[0][jj];
             a_aff = uniform(wave_min(a.alpha[0]));
@@ -2624,13 +2753,12 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
         SUB_END(25);
         // ================= F (both): corrector and centring-only steps, their lengths =================
         double alpha1, alpha2;
-        double dvo[2][NZ], dpo[2][NX];
+        double dvo[2][NZ];
         {
             FIn<NH, 2> ld = {};
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 ld.x[i] = R.x[i]; ld.rb[i] = t.rb[i]; ld.kg[0][i] = ro.K[0][i]; ld.kg[1][i] = ro.K[1][i];
-                ld.pv[0][i] = o1[i]; ld.pv[1][i] = o2[i];
             }
             ld.u[0] = R.u[0]; ld.u[1] = R.u[1];
             ld.kv[0][0] = kvo[0][0]; ld.kv[0][1] = kvo[0][1]; ld.kv[1][0] = kvo[1][0]; ld.kv[1][1] = kvo[1][1];
@@ -2641,8 +2769,6 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
                 ld.ll[r] = R.ll[r]; ld.lu[r] = R.lu[r]; ld.tl[r] = R.tl[r]; ld.tu[r] = R.tu[r];
                 ld.til_[r] = R.til_[r]; ld.tiu_[r] = R.tiu_[r];
             }
-#pragma unroll
-            for (int i = 0; i < 15; ++i) ld.Pk[i] = Po[i];
             ld.ab = R.ab;
             double dxi[2][NX], dxo[2][NX];
 #pragma unroll
@@ -2670,10 +2796,8 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             for (int q = 0; q < 2; ++q) {
 #pragma unroll
                 for (int jj = 0; jj < NZ; ++jj) dvo[q][jj] = 0.0;
-#pragma unroll
-                for (int i = 0; i < NX; ++i) dpo[q][i] = 0.0;
             }
-            if (on) stage_F_compute<NH, ANY, 2, false, true>(S, o, pc, 0, sigma_mu, ld, dxi, a, kr, dvo, dpo);
+            if (on) stage_F_compute<NH, ANY, 2, false, true>(S, o, pc, 0, sigma_mu, ld, dxi, a, kr, dvo);
             alpha1 = uniform(wave_min(a.alpha[0]));
             alpha2 = uniform(wave_min(a.alpha[1]));
         }
@@ -2685,8 +2809,6 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
         ++done;
 #pragma unroll
         for (int jj = 0; jj < NZ; ++jj) R.dv[jj] = use2 ? dvo[1][jj] : dvo[0][jj];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) dpi[i] = use2 ? dpo[1][i] : dpo[0][i];
         if (!(alpha > o.alpha_min)) {      // minimum step or NaN
             add_total = qit;
             add_sqp = 1;
@@ -2713,7 +2835,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             stw<ANY>(S, 0, M::QPI + i, R.qpi[i]);
-            *wsp(S, 0, M::DPI + i, 512u * (unsigned)sol) = dpi[i];
+            stw<ANY>(S, 0, M::RG + NU + i, R.rgo[i]);
         }
 #pragma unroll
         for (int r = 0; r < M::R; ++r) {
@@ -3106,13 +3228,14 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             const int kj = k0 + (int)threadIdx.x;
             if (kj > N) continue;
             const Lane S = stage_lane(C, (unsigned)kj), D = stage_lane(R, (unsigned)kj);
-            // what is alive between two interior-point iterations: the linearisation, the iterate and the
-            // pending step (fields X .. TU and DV .. the end); residuals, factors and right-hand sides are
-            // formed anew by the next iteration's first sweep before anything reads them.  In the
+            // what is alive between two interior-point iterations: the linearisation, the iterate, the
+            // stationarity residual and the pending step (fields X .. RG and DV .. the end); the other
+            // residuals, factors and right-hand sides are formed anew by the next iteration's first sweep
+            // before anything reads them.  In the
             // [stage][field][lane] layout every word of a problem sits in a cache line of its own, so a
             // word not copied is a line not fetched.
             for (int part = 0; part < 2; ++part) {
-                const int lo = part ? M::DV : M::X, hi = part ? M::F : M::TU + M::R;
+                const int lo = part ? M::DV : M::X, hi = part ? M::F : M::RG + NZ;
                 for (int f0 = lo; f0 < hi; f0 += 16) {
                     double tmp[16];
 #pragma unroll

@@ -721,13 +721,25 @@ static void riccati_solve(const problem *pb, stage *st)
             for (int c = 0; c < NU; ++c) acc = rfma(s->B[i][c], s->dv[c], acc);
             n->dv[NU + i] = acc;
         }
-        for (int i = 0; i < NX; ++i) {
-            real acc = n->p[i];
-            for (int j = 0; j < NX; ++j) acc = rfma(n->P[i][j], n->dv[NU + j], acc);
-            n->dpi[i] = acc;
-        }
     }
     st[N].dv[0] = st[N].dv[1] = (real)0.0;
+    /* step of the dynamics multipliers: the x_k block of the Newton system,
+     *   Ht_xx dx_k + A_k' dpi_(k+1) - dpi_k = -gt_x,
+     * solved for dpi_k from the last stage backwards (equal to P_k dx_k + p_k in exact
+     * arithmetic; this form needs neither P nor p once the forward pass is done) */
+    for (int k = N; k >= 1; --k) {
+        stage *s = &st[k];
+        const real *dx = &s->dv[NU];
+        for (int i = 0; i < NX; ++i) {
+            real acc = s->gt[NU + i];
+            if (i == 0) acc = rfma(s->hxy, dx[1], rfma(Ht_entry(s, 2, 2), dx[0], acc));
+            else if (i == 1) acc = rfma(Ht_entry(s, 3, 3), dx[1], rfma(s->hxy, dx[0], acc));
+            else acc = rfma(s->Ht[NU + i], dx[i], acc);
+            if (k < N)
+                for (int r = 0; r < NX; ++r) acc = rfma(s->A[r][i], st[k + 1].dpi[r], acc);
+            s->dpi[i] = acc;
+        }
+    }
 }
 
 /* step of the slacks and multipliers implied by dv, longest feasible step,
