@@ -6,7 +6,7 @@
 //  * one LANE per problem (the bulk of a large batch).  The Riccati recursion is a
 //    serial chain over the N stages of ONE problem; 64 independent chains keep every
 //    FP64 instruction full.  The price is that a lane's working set (iterate,
-//    linearisation, multipliers and Riccati factors of all N+1 stages, ~1.2 KB per
+//    linearisation, multipliers and Riccati factors of all N+1 stages, ~1.0 KB per
 //    stage) cannot live on chip: it sits in an HBM workspace laid out
 //    [wave][stage][field][lane], so each wavefront load/store is one contiguous
 //    512-byte segment (with the non-temporal hint: nothing is reused before megabytes
@@ -15,8 +15,10 @@
 //
 //      L   forward : apply the SQP step, RK4 + sensitivities, NLP residuals,
 //                    cold start of the interior point (one per SQP iteration)
-//      B0  backward: apply the previous interior-point step, residuals, barrier
-//                    Hessian, Riccati factorisation + backward substitution
+//      B0  backward: apply the previous interior-point step (the step of the dynamics
+//                    multipliers is formed here, from the stationarity of the Newton
+//                    system it solves), residuals, barrier Hessian, Riccati
+//                    factorisation + backward substitution
 //      F   forward : affine step, its longest feasible length, centring sums
 //      Bs  backward: corrector AND centring-only right-hand sides, both substituted
 //      F   forward : both steps and their lengths (the centring-only one is taken
