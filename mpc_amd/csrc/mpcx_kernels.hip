@@ -2993,7 +2993,8 @@ __device__ __attribute__((noinline)) void coop_M(COOP_PARAMS, double alpha, ldou
 template <int NH>
 __global__ void __launch_bounds__(64) __attribute__((disable_tail_calls))
 mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
-                int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots, unsigned deal, int burst_few)
+                int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots, unsigned deal, int burst_few,
+                double hold_alpha, int hold_extra)
 {
     const mpcx_opts &o = *op;
     typedef Map<NH> M;
@@ -3562,7 +3563,10 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                 // problems in regions take all their iterations here; of the others, the oldest
                 // boost_lanes (they move to a region if one is free)
                 const unsigned long long sm = __ballot(live && solo);
-                const unsigned long long cm = (n_new < boost_lanes) ? __ballot(live && !solo && age >= boost_min) : 0ull;
+                // (a QP whose steps have collapsed is about to be given up -- a handful of iterations more --
+                // and is not worth a region: it stays with the one-lane-per-problem sweeps a while longer)
+                const bool held = (state == LS_QP) && sp.have && (sp.alpha < hold_alpha) && (age < boost_min + hold_extra);
+                const unsigned long long cm = (n_new < boost_lanes) ? __ballot(live && !solo && age >= boost_min && !held) : 0ull;
                 if ((sm | cm) == 0) break;
                 int p = -1, best = -1;
                 if (sm != 0) {
@@ -3700,6 +3704,14 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     int burst_few = 8;
     if (const char *e = getenv("MPCX_BURST")) { int v = atoi(e); if (v >= 0 && v <= 1024) burst_few = v; }
 
+    // "alpha,extra": a problem inside a QP whose last step was shorter than alpha is left to the
+    // one-lane-per-problem sweeps until it is `extra` iterations past the ageing threshold (alpha 0: off)
+    double hold_alpha = 0.001;
+    int hold_extra = 48;
+    if (const char *e = getenv("MPCX_HOLD")) {
+        double a = 0.0; int x = 0;
+        if (sscanf(e, "%lf,%d", &a, &x) == 2 && a >= 0.0 && x >= 0) { hold_alpha = a; hold_extra = x; }
+    }
     int svc_min = MPCX_SERVICE_MIN;
     if (const char *e = getenv("MPCX_SVC_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) svc_min = v; }
     if (coop_max < 0 || coop_max > 64) return hipErrorInvalidValue;
@@ -3730,12 +3742,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     }
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra); break;
 #else
     default: return hipErrorInvalidValue;
 #endif
