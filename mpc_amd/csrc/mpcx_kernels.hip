@@ -2983,7 +2983,7 @@ __device__ __attribute__((noinline)) void coop_M(COOP_PARAMS, double alpha, ldou
 // Write-out, fetch and sweep L ("service") run with few lanes each, so they are held
 // back until this many lanes wait for them (or no lane has interior-point work).
 #ifndef MPCX_SERVICE_MIN
-#define MPCX_SERVICE_MIN 4
+#define MPCX_SERVICE_MIN 8
 #endif
 // (coop_max: with this many problems or fewer in progress the wavefront takes them one at a
 // time in single-problem mode.)
