@@ -765,9 +765,11 @@ struct LAcc { double rs, re, ri, rc, cost; };
 
 // nxt (single-problem mode only): state, step and multiplier of stage k+1, read by the caller
 // before any lane has overwritten them; otherwise they are loaded here
+// first: the problem's first linearisation.  Its multipliers are zero by definition and are not read from
+// the workspace (nothing has been written there yet); zero_u: nor are its inputs (no input guess given)
 // alpha: length of the SQP step (1 unless the line search shortened it; 1 * v is v exactly)
 template <int NH, int KIND, bool COOP = false>
-DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, bool first, double alpha,
+DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, bool first, bool zero_u, double alpha,
                  double *xk, double *pik, LAcc &a, const KR &kr = KR{false, false}, const double *nxt = nullptr)
 {
     typedef Map<NH> M;
@@ -796,6 +798,14 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
         lu[r] = ldw<KIND>(L, k, M::LAMU + r);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (KIND != LAST) {
+#pragma unroll
+        for (int c = 0; c < NU; ++c) uk[c] = (first && zero_u) ? 0.0 : uk[c];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) pin1[i] = first ? 0.0 : pin1[i];
+    }
+#pragma unroll
+    for (int r = 0; r < M::R; ++r) { ll[r] = first ? 0.0 : ll[r]; lu[r] = first ? 0.0 : lu[r]; }
     // SQP step (nothing to add before the first QP; v is uninitialised then)
     AB ab = {};
     if (KIND != LAST) {
@@ -928,7 +938,7 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
 // allocation; arguments travel by value in registers and results come back through a
 // small per-lane LDS area `ret` ([slot][lane] doubles), never through the stack.
 template <int NH>
-__device__ __attribute__((noinline)) void sweep_L(Lane L, PC<NH> pc, const mpcx_opts *op, bool first, double alpha,
+__device__ __attribute__((noinline)) void sweep_L(Lane L, PC<NH> pc, const mpcx_opts *op, bool first, bool zero_u, double alpha,
                                                   ldouble *ret)
 {
     const mpcx_opts ol = opts_in_registers(op);
@@ -943,9 +953,9 @@ __device__ __attribute__((noinline)) void sweep_L(Lane L, PC<NH> pc, const mpcx_
         xk[i] = first ? x0 : x0 + alpha * v0;
         pik[i] = 0.0;
     }
-    stage_L<NH, FIRST>(L, o, pc, 0, first, alpha, xk, pik, a);
-    for (int k = 1; k < N; ++k) stage_L<NH, MID>(L, o, pc, k, first, alpha, xk, pik, a);
-    stage_L<NH, LAST>(L, o, pc, N, first, alpha, xk, pik, a);
+    stage_L<NH, FIRST>(L, o, pc, 0, first, zero_u, alpha, xk, pik, a);
+    for (int k = 1; k < N; ++k) stage_L<NH, MID>(L, o, pc, k, first, zero_u, alpha, xk, pik, a);
+    stage_L<NH, LAST>(L, o, pc, N, first, zero_u, alpha, xk, pik, a);
     ret[0 * 64] = a.rs; ret[1 * 64] = a.re; ret[2 * 64] = a.ri; ret[3 * 64] = a.rc;
     ret[4 * 64] = a.cost;
 }
@@ -2861,7 +2871,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
 // sweep L has no recursion: every stage is linearised at its own (new) state, which its lane
 // forms from the stage's own iterate and step exactly as the stage before would have
 template <int NH, bool ONE>
-__device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, const mpcx_opts *op, bool first, double alpha, ldouble *ret)
+__device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, const mpcx_opts *op, bool first, bool zero_u, double alpha, ldouble *ret)
 {
     typedef Map<NH> M;
     COOP_UNPACK(NH);
@@ -2883,7 +2893,7 @@ __device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, const mpcx_opts *o
             for (int i = 0; i < NX; ++i) {
                 const double x0 = ldw<ANY>(S, 0, M::X + i), v0 = ldw<ANY>(S, 0, M::V + NU + i), q0 = ldw<ANY>(S, 0, M::QPI + i);
                 xk[i] = first ? x0 : x0 + alpha * v0;
-                pik[i] = (kj > 0) ? q0 : 0.0;
+                pik[i] = (kj > 0 && !first) ? q0 : 0.0;
             }
         }
         if (kj < N) {
@@ -2898,7 +2908,7 @@ __device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, const mpcx_opts *o
         coop_sync();
         LAcc a = {0.0, 0.0, 0.0, 0.0, 0.0};
         const KR kr = {kj == 0, kj == N};
-        if (kj <= N) stage_L<NH, ANY, true>(S, o, pc, 0, first, alpha, xk, pik, a, kr, nxt);
+        if (kj <= N) stage_L<NH, ANY, true>(S, o, pc, 0, first, zero_u, alpha, xk, pik, a, kr, nxt);
         const int kend = (N - k0 < 63) ? N - k0 : 63;
         tot.rs = dmax(tot.rs, wave_max(a.rs)); tot.re = dmax(tot.re, wave_max(a.re));
         tot.ri = dmax(tot.ri, wave_max(a.ri)); tot.rc = dmax(tot.rc, wave_max(a.rc));
@@ -3022,6 +3032,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
     L.nobs = 0;
     L.h = L.hh = L.h6 = L.hB = L.invL = 0.0;
 
+    const bool zero_u = (in.uguess == nullptr);      // no input guess: a problem's first linearisation takes u = 0
     int state = ((int)threadIdx.x < lanes) ? LS_FETCH : LS_DONE;
     int status = MPCX_MAXITER, sqp_it = 0, qp_it = 0, qp_total = 0, m_total = 0;
     bool first = true, fresh = false;
@@ -3086,8 +3097,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             if ((int)threadIdx.x == p) ls_rho = rho;
         }
         SUB_BEGIN();
-        if (N < 64) coop_L<NH, true>(COOP_PASS(C, pcc), op, fp, alpha, ret);
-        else coop_L<NH, false>(COOP_PASS(C, pcc), op, fp, alpha, ret);
+        if (N < 64) coop_L<NH, true>(COOP_PASS(C, pcc), op, fp, zero_u, alpha, ret);
+        else coop_L<NH, false>(COOP_PASS(C, pcc), op, fp, zero_u, alpha, ret);
         SUB_END(28);
         const double r0 = uniform(ret[0 * 64]), r1 = uniform(ret[1 * 64]), r2 = uniform(ret[2 * 64]),
                      r3 = uniform(ret[3 * 64]), r4 = uniform(ret[4 * 64]);
@@ -3392,22 +3403,18 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                     } else {
                         guess_node(G, kj, N, xg);
                     }
+                    // (the state guess, and the input guess if there is one; the first linearisation takes the
+                    // multipliers, and the inputs otherwise, as zero without reading them)
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) {
-                        stw<ANY>(S, 0, M::X + i, xg[i]);
-                        stw<ANY>(S, 0, M::QPI + i, 0.0);
-                    }
-                    double ug[NU] = {0.0, 0.0};
-                    if (in.uguess && kj < N) {
-                        ug[0] = in.uguess[((size_t)kj * NU + 0) * L.B + b];
-                        ug[1] = in.uguess[((size_t)kj * NU + 1) * L.B + b];
-                    }
-                    stw<ANY>(S, 0, M::U + 0, ug[0]);
-                    stw<ANY>(S, 0, M::U + 1, ug[1]);
-#pragma unroll
-                    for (int r = 0; r < M::R; ++r) {
-                        stw<ANY>(S, 0, M::LAML + r, 0.0);
-                        stw<ANY>(S, 0, M::LAMU + r, 0.0);
+                    for (int i = 0; i < NX; ++i) stw<ANY>(S, 0, M::X + i, xg[i]);
+                    if (in.uguess) {
+                        double ug[NU] = {0.0, 0.0};
+                        if (kj < N) {
+                            ug[0] = in.uguess[((size_t)kj * NU + 0) * L.B + b];
+                            ug[1] = in.uguess[((size_t)kj * NU + 1) * L.B + b];
+                        }
+                        stw<ANY>(S, 0, M::U + 0, ug[0]);
+                        stw<ANY>(S, 0, M::U + 1, ug[1]);
                     }
                 }
             }
@@ -3445,14 +3452,14 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                 if (o.rti && !first) {
                     // real-time iteration: apply the one step, report the new objective
                     if (!coop_lin && !solo) {
-                        sweep_L<NH>(L, pc, op, false, 1.0, ret);
+                        sweep_L<NH>(L, pc, op, false, zero_u, 1.0, ret);
                         cost = ret[4 * 64];
                     }
                     status = MPCX_SUCCESS;
                     state = LS_OUT;
                 } else {
                     if (!coop_lin && !solo) {
-                        sweep_L<NH>(L, pc, op, first, step_alpha, ret);
+                        sweep_L<NH>(L, pc, op, first, zero_u, step_alpha, ret);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) res[i] = ret[i * 64];
                         cost = ret[4 * 64];
