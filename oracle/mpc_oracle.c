@@ -675,6 +675,7 @@ static void riccati_factor(const problem *pb, stage *st)
     }
 }
 
+static int g_dpi_costate = 0;     /* MPCX_ORACLE_DPI_COSTATE, see riccati_solve() */
 /* backward + forward substitution with the stored factors; result in dv, dpi */
 static void riccati_solve(const problem *pb, stage *st)
 {
@@ -723,6 +724,19 @@ static void riccati_solve(const problem *pb, stage *st)
         }
     }
     st[N].dv[0] = st[N].dv[1] = (real)0.0;
+    if (g_dpi_costate) {
+        /* study switch (MPCX_ORACLE_DPI_COSTATE=1; never set by the product or the parity tests): the
+         * form HPIPM uses, dpi_k = P_k dx_k + p_k */
+        for (int k = 1; k <= N; ++k) {
+            stage *n = &st[k];
+            for (int i = 0; i < NX; ++i) {
+                real acc = n->p[i];
+                for (int j = 0; j < NX; ++j) acc = rfma(n->P[i][j], n->dv[NU + j], acc);
+                n->dpi[i] = acc;
+            }
+        }
+        return;
+    }
     /* step of the dynamics multipliers: the x_k block of the Newton system,
      *   Ht_xx dx_k + A_k' dpi_(k+1) - dpi_k = -gt_x,
      * solved for dpi_k from the last stage backwards (equal to P_k dx_k + p_k in exact
@@ -1123,6 +1137,7 @@ int mpcx_oracle_solve_batch(const mpcx_batch *in, const mpcx_opts *o, mpcx_resul
     g_debug = getenv("MPCX_ORACLE_DEBUG") ? atoi(getenv("MPCX_ORACLE_DEBUG")) : 0;
     g_stage0_rows = getenv("MPCX_ORACLE_STAGE0_ROWS") ? atoi(getenv("MPCX_ORACLE_STAGE0_ROWS")) : 0;
     g_cond_blocks = getenv("MPCX_ORACLE_COND_BLOCKS") ? atoi(getenv("MPCX_ORACLE_COND_BLOCKS")) : 0;
+    g_dpi_costate = getenv("MPCX_ORACLE_DPI_COSTATE") ? atoi(getenv("MPCX_ORACLE_DPI_COSTATE")) : 0;
     const int N = in->N, B = in->B;
     int fail = 0;
 #ifdef _OPENMP

@@ -132,6 +132,23 @@ def test_fetch_order_leaves_no_trace(oracle, monkeypatch):
     cases.assert_same_solution(dealt, ref, f"synthetic B={B}")
 
 
+@pytest.mark.parametrize("hold", ["0,0", "0.5,8", "1e-3,1000"])
+def test_hold_policy_leaves_no_trace(oracle, monkeypatch, hold):
+    """Which problems are aged into single-problem mode is scheduling only: no ageing hold (0,0), a hold
+    that keeps almost every QP in the one-lane-per-problem sweeps for 8 more iterations, and one that never
+    releases a collapsed QP give the default's results, which are the oracle's."""
+    B = 40000
+    packed = synthetic_batch(B)
+    base = _lib.solve_packed(packed)
+    monkeypatch.setenv("MPCX_HOLD", hold)
+    other = _lib.solve_packed(packed)
+    monkeypatch.delenv("MPCX_HOLD")
+    cases.assert_same_solution(base, other, f"hold policy {hold} vs default")
+    if hold == "0,0":
+        ref = oracle.solve_packed(packed)
+        cases.assert_same_solution(base, ref, f"synthetic B={B}")
+
+
 @pytest.mark.parametrize("B", [64, 3000])
 def test_synthetic_obstacle_batch_matches_oracle(oracle, B):
     """The benchmark's second workload: one obstacle per problem beside the middle of the path."""

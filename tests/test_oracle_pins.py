@@ -140,3 +140,27 @@ def test_partial_condensing_emulated_changes_no_outcome(oracle, monkeypatch):
     ok = plain["status"] == 0
     assert np.abs(cond["X"][ok] - plain["X"][ok]).max() < 1e-5
     assert not np.array_equal(cond["qp_iter"], plain["qp_iter"])      # the switch does change the path
+
+
+def test_multiplier_step_forms_agree(oracle, monkeypatch):
+    """The step of the dynamics multipliers is solved backwards from the x-blocks of the Newton system
+    (dpi_k = gt_x + Ht_xx dx_k + A_k' dpi_(k+1)); HPIPM forms it as P_k dx_k + p_k.  The two are equal in
+    exact arithmetic: with the oracle's study switch for the second form the recorded numbers are met as
+    before, a benchmark sample ends with the same statuses and SQP counts, and converged trajectories
+    agree to rounding."""
+    from mpc_amd.synthetic import synthetic_batch
+    sample = synthetic_batch(3000)
+    plain = oracle.solve_packed(sample)
+    monkeypatch.setenv("MPCX_ORACLE_DPI_COSTATE", "1")
+    for name in ("line", "E_to_F"):
+        (status, res), pin = _solve(name, oracle), PINS[name]
+        assert status == pin["status"]
+        assert np.abs(res["x"][1] - pin["x1"]).max() < TOL and np.abs(res["x"][-1] - pin["xN"]).max() < TOL
+        assert np.abs(res["u"][0] - pin["u0"]).max() < TOL and np.abs(res["u"][-1] - pin["u_last"]).max() < TOL
+    other = oracle.solve_packed(sample)
+    assert np.array_equal(other["status"], plain["status"]) and np.array_equal(other["sqp_iter"], plain["sqp_iter"])
+    ok = plain["status"] == 0
+    assert ok.sum() > 100
+    assert np.abs(other["X"][ok] - plain["X"][ok]).max() < 1e-7
+    assert np.abs(other["U"][ok] - plain["U"][ok]).max() < 1e-7
+    assert not np.array_equal(other["X"], plain["X"])      # the switch does change the rounding
