@@ -177,28 +177,33 @@ DEV gdouble *wsp(const Lane &L, int k, int f, unsigned extra)
 // Stage code is instantiated per kind of stage: FIRST / MID / LAST in one-lane-per-problem
 // mode, where the kind is known at compile time, and ANY in single-problem mode, where each
 // lane has a stage of its own and the kind is a run-time value.
-enum { FIRST = 0, MID = 1, LAST = 2, ANY = 3 };
+enum { FIRST = 0, MID = 1, LAST = 2, ANY = 3, MIDC = 4 };
 // Workspace accesses.  In one-lane-per-problem mode a wavefront streams through megabytes
 // between two uses of the same word, so those accesses carry the non-temporal hint and do not
 // push the single-problem regions (reused every ~100 us) out of the L2.
 #ifndef MPCX_STREAM_HINT
 #define MPCX_STREAM_HINT 1
 #endif
+// ... except in the stages at the two ends of a sweep (the first and the last stage and this many next to
+// each): the next sweep runs the other way and starts with what this one has just touched.
+#ifndef MPCX_EDGE_STAGES
+#define MPCX_EDGE_STAGES 8
+#endif
 template <int KIND> DEV double ldw(const Lane &L, int k, int f)
 {
-    if (MPCX_STREAM_HINT && KIND != ANY) return __builtin_nontemporal_load(wsp(L, k, f, 0u));
+    if (MPCX_STREAM_HINT && KIND == MID) return __builtin_nontemporal_load(wsp(L, k, f, 0u));
     return *wsp(L, k, f, 0u);
 }
 template <int KIND> DEV void stw(const Lane &L, int k, int f, double v)
 {
-    if (MPCX_STREAM_HINT && KIND != ANY) __builtin_nontemporal_store(v, wsp(L, k, f, 0u));
+    if (MPCX_STREAM_HINT && KIND == MID) __builtin_nontemporal_store(v, wsp(L, k, f, 0u));
     else *wsp(L, k, f, 0u) = v;
 }
 DEV double ldp(const Lane &L, int f) { return (L.pdata + (size_t)f * L.B)[L.b]; }
 // field f + df where df differs from lane to lane
 template <int KIND> DEV double ldw_lane(const Lane &L, int k, int f, int df)
 {
-    if (MPCX_STREAM_HINT && KIND != ANY) return __builtin_nontemporal_load(wsp(L, k, f, 512u * (unsigned)df));
+    if (MPCX_STREAM_HINT && KIND == MID) return __builtin_nontemporal_load(wsp(L, k, f, 512u * (unsigned)df));
     return *wsp(L, k, f, 512u * (unsigned)df);
 }
 
@@ -582,7 +587,7 @@ struct KR { bool first, last; };
 
 template <int KIND> DEV constexpr bool row_present(int r)      // can a stage of this kind have row r
 {
-    return (KIND == ANY) ? true : (r < NU) ? (KIND != LAST) : (r < 9) ? (KIND != FIRST) : (KIND == MID);
+    return (KIND == ANY) ? true : (r < NU) ? (KIND != LAST) : (r < 9) ? (KIND != FIRST) : (KIND == MID || KIND == MIDC);
 }
 template <int KIND> DEV constexpr bool var_present(int j)      // ... have v[j] as a variable
 {
@@ -954,7 +959,12 @@ __device__ __attribute__((noinline)) void sweep_L(Lane L, PC<NH> pc, const mpcx_
         pik[i] = 0.0;
     }
     stage_L<NH, FIRST>(L, o, pc, 0, first, zero_u, alpha, xk, pik, a);
-    for (int k = 1; k < N; ++k) stage_L<NH, MID>(L, o, pc, k, first, zero_u, alpha, xk, pik, a);
+    {
+        int k = 1;
+        for (; k < N && k <= MPCX_EDGE_STAGES; ++k) stage_L<NH, MIDC>(L, o, pc, k, first, zero_u, alpha, xk, pik, a);
+        for (; k < N - MPCX_EDGE_STAGES; ++k) stage_L<NH, MID>(L, o, pc, k, first, zero_u, alpha, xk, pik, a);
+        for (; k < N; ++k) stage_L<NH, MIDC>(L, o, pc, k, first, zero_u, alpha, xk, pik, a);
+    }
     stage_L<NH, LAST>(L, o, pc, N, first, zero_u, alpha, xk, pik, a);
     ret[0 * 64] = a.rs; ret[1 * 64] = a.re; ret[2 * 64] = a.ri; ret[3 * 64] = a.rc;
     ret[4 * 64] = a.cost;
@@ -1601,7 +1611,12 @@ __device__ __attribute__((noinline)) void sweep_B0(Lane L, PC<NH> pc, const mpcx
         _Pragma("unroll") for (int i = 0; i < NX; ++i) { vxn[i] = t.vx[i]; qpin[i] = t.qpi[i]; } \
     }
     B0_STAGE(LAST, N)
-    for (int k = N - 1; k >= 1; --k) B0_STAGE(MID, k)
+    {
+        int k = N - 1;
+        for (; k >= 1 && k >= N - MPCX_EDGE_STAGES; --k) B0_STAGE(MIDC, k)
+        for (; k > MPCX_EDGE_STAGES; --k) B0_STAGE(MID, k)
+        for (; k >= 1; --k) B0_STAGE(MIDC, k)
+    }
     B0_STAGE(FIRST, 0)
 #undef B0_STAGE
     ret[0 * 64] = ng; ret[1 * 64] = nb; ret[2 * 64] = nd; ret[3 * 64] = nm;
@@ -1785,7 +1800,12 @@ __device__ __attribute__((noinline)) void sweep_Bs(Lane L, PC<NH> pc, const mpcx
 #pragma unroll
     for (int i = 0; i < NX; ++i) { pn1[i] = 0.0; pn2[i] = 0.0; }
     stage_Bs<NH, LAST>(L, o, pc, N, sigma_mu, pn1, pn2);
-    for (int k = N - 1; k >= 1; --k) stage_Bs<NH, MID>(L, o, pc, k, sigma_mu, pn1, pn2);
+    {
+        int k = N - 1;
+        for (; k >= 1 && k >= N - MPCX_EDGE_STAGES; --k) stage_Bs<NH, MIDC>(L, o, pc, k, sigma_mu, pn1, pn2);
+        for (; k > MPCX_EDGE_STAGES; --k) stage_Bs<NH, MID>(L, o, pc, k, sigma_mu, pn1, pn2);
+        for (; k >= 1; --k) stage_Bs<NH, MIDC>(L, o, pc, k, sigma_mu, pn1, pn2);
+    }
     stage_Bs<NH, FIRST>(L, o, pc, 0, sigma_mu, pn1, pn2);
 }
 
@@ -2017,7 +2037,12 @@ __device__ __attribute__((noinline)) double sweep_F(Lane L, PC<NH> pc, const mpc
 #pragma unroll
         for (int i = 0; i < NX; ++i) dx[q][i] = 0.0;
     stage_F<NH, FIRST, NS>(L, o, pc, 0, sigma_mu, dx, a);
-    for (int k = 1; k < N; ++k) stage_F<NH, MID, NS>(L, o, pc, k, sigma_mu, dx, a);
+    {
+        int k = 1;
+        for (; k < N && k <= MPCX_EDGE_STAGES; ++k) stage_F<NH, MIDC, NS>(L, o, pc, k, sigma_mu, dx, a);
+        for (; k < N - MPCX_EDGE_STAGES; ++k) stage_F<NH, MID, NS>(L, o, pc, k, sigma_mu, dx, a);
+        for (; k < N; ++k) stage_F<NH, MIDC, NS>(L, o, pc, k, sigma_mu, dx, a);
+    }
     stage_F<NH, LAST, NS>(L, o, pc, N, sigma_mu, dx, a);
     if (NS == 1) { ret[0 * 64] = a.s1; ret[1 * 64] = a.s2; }
     else ret[0 * 64] = a.alpha[1];
