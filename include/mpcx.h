@@ -149,7 +149,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts,
  * `stream` (a hipStream_t, NULL = default stream) and the call returns.
  * `workspace` must hold mpcx_workspace_bytes(B, N) bytes, 256-byte aligned.
  * N is limited by the 32-bit byte offsets the kernels address a wavefront's workspace with:
- * every solve entry point returns MPCX_E_BADARG for N > mpcx_max_horizon() (about 41 000).
+ * every solve entry point returns MPCX_E_BADARG for N > mpcx_max_horizon() (about 51 000).
  */
 int    mpcx_max_horizon(void);
 size_t mpcx_workspace_bytes(int32_t B, int32_t N);
