@@ -149,7 +149,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts,
  * `stream` (a hipStream_t, NULL = default stream) and the call returns.
  * `workspace` must hold mpcx_workspace_bytes(B, N) bytes, 256-byte aligned.
  * N is limited by the 32-bit byte offsets the kernels address a wavefront's workspace with:
- * every solve entry point returns MPCX_E_BADARG for N > mpcx_max_horizon() (about 51 000).
+ * every solve entry point returns MPCX_E_BADARG for N > mpcx_max_horizon() (about 54 000).
  */
 int    mpcx_max_horizon(void);
 size_t mpcx_workspace_bytes(int32_t B, int32_t N);
@@ -165,9 +165,9 @@ int    mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts,
  * memory on every GPU the library is loaded on; the call makes no hipMalloc / hipFree, no copy from
  * host memory and no other allocating call, and queues its kernels on `stream`.  The first call
  * on a device looks the array's address up (make it outside a graph capture).
- * Limits: the scratch must hold one wavefront's share, which bounds N (N <= 790 or so; larger N
+ * Limits: the scratch must hold one wavefront's share, which bounds N (N <= 830 or so; larger N
  * returns MPCX_E_BADARG); B is not limited, but only as many wavefronts run as the scratch holds
- * (15 at N = 50), so large batches are slow here.  All calls on one GPU share the array: calls
+ * (16 at N = 50), so large batches are slow here.  All calls on one GPU share the array: calls
  * that overlap in time on the same GPU (different streams or threads) race and must not be made.
  */
 #define MPCX_STATIC_SCRATCH_BYTES (64u << 20)

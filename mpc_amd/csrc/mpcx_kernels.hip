@@ -88,10 +88,9 @@ struct Map {
     static constexpr int RS = MPCX_STORE_RECIP ? R : 0;
     static constexpr int TIL = TU + R;         // RS 1 / slack (only if stored, see MPCX_STORE_RECIP)
     static constexpr int TIU = TIL + RS;       // RS
-    static constexpr int RG = TIU + RS;        // 7  stationarity residual
-    static constexpr int RB = RG + 7;          // 5  dynamics residual
-    static constexpr int PRB = RB + 5;         // 5  P(k+1) * rb
-    static constexpr int K = PRB + 5;          // 10 feedback gain, row-major [2][5]
+    static constexpr int RG = TIU + RS;        // 5  stationarity residual, state part (what the next backward sweep reads)
+    static constexpr int RB = RG + 5;          // 5  dynamics residual
+    static constexpr int K = RB + 5;           // 10 feedback gain, row-major [2][5]
     static constexpr int LDL = K + 10;         // 3  l10, 1/d0, 1/d1 of the LDL' of M_uu
     static constexpr int KV = LDL + 3;         // 2  feed-forward
     static constexpr int DV = KV + 2;          // 7  step
@@ -1134,7 +1133,7 @@ DEV void stage_B0_load(const Lane &L, int k, const Step &sp, B0In<NH> &in, const
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         qpi[i] = (KIND != FIRST) ? ldw<KIND>(L, k, M::QPI + i) : 0.0;
-        in.rgo[i] = (KIND != FIRST) ? ldw<KIND>(L, k, M::RG + NU + i) : 0.0;
+        in.rgo[i] = (KIND != FIRST) ? ldw<KIND>(L, k, M::RG + i) : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
@@ -1367,7 +1366,7 @@ DEV void stage_B0_tail(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int 
     double gt[NZ];
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
-        if (ST) stw<KIND>(L, k, M::RG + j, rg[j]);
+        if (ST && j >= NU) stw<KIND>(L, k, M::RG + j - NU, rg[j]);
         out.rg[j] = rg[j];
         if (var_present<KIND>(j)) out.ng = var_on<KIND>(kr, j) ? dmax(out.ng, dabs(rg[j])) : out.ng;
         gt[j] = rg[j];
@@ -1572,7 +1571,6 @@ DEV void store_ric(const Lane &L, int k, bool factors, const RicOut &ro)
     if (factors) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            stw<KIND>(L, k, M::PRB + i, ro.prb[i]);
             stw<KIND>(L, k, M::K + i, ro.K[0][i]);
             stw<KIND>(L, k, M::K + NX + i, ro.K[1][i]);
         }
@@ -1626,7 +1624,7 @@ __device__ __attribute__((noinline)) void sweep_B0(Lane L, PC<NH> pc, const mpcx
 // Bs: right-hand sides of the corrector (1) and of the centring-only step (2), both
 // substituted backwards with the stored factors in the same pass over the data
 struct BsOut {
-    double gt1[NZ], gt2[NZ], prb[NX], k0[NX], k1[NX], l10, d0, d1;
+    double gt1[NZ], gt2[NZ], k0[NX], k1[NX], l10, d0, d1;
     AB ab;
 };
 
@@ -1644,7 +1642,6 @@ DEV void stage_Bs_load(const Lane &L, int k, BsIn<NH> &in, BsOut &out, const KR 
 {
     typedef Map<NH> M;
     double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&dva)[NZ] = in.dva;
-    double *gt1 = out.gt1;
     double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
            (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
     load_xu<NH, KIND>(L, k, kr, x, u);
@@ -1652,7 +1649,6 @@ DEV void stage_Bs_load(const Lane &L, int k, BsIn<NH> &in, BsOut &out, const KR 
     for (int j = 0; j < NZ; ++j) {
         v[j] = ldw<KIND>(L, k, M::V + j);
         dva[j] = ldw<KIND>(L, k, M::DVA + j);
-        gt1[j] = ldw<KIND>(L, k, M::RG + j);
     }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
@@ -1670,12 +1666,11 @@ DEV void stage_Bs_load(const Lane &L, int k, BsIn<NH> &in, BsOut &out, const KR 
     out.ab = AB{};
     out.l10 = 0.0; out.d0 = 1.0; out.d1 = 1.0;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { out.prb[i] = 0.0; out.k0[i] = 0.0; out.k1[i] = 0.0; }
+    for (int i = 0; i < NX; ++i) { out.k0[i] = 0.0; out.k1[i] = 0.0; }
     if (KIND != LAST) {
         load_ab<NH, KIND>(L, k, out.ab);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            out.prb[i] = ldw<KIND>(L, k, M::PRB + i);
             out.k0[i] = ldw<KIND>(L, k, M::K + i);
             out.k1[i] = ldw<KIND>(L, k, M::K + NX + i);
         }
@@ -1686,7 +1681,10 @@ DEV void stage_Bs_load(const Lane &L, int k, BsIn<NH> &in, BsOut &out, const KR 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Bs, row part of stage k: the two right-hand sides; out.gt1 holds the stationarity residual on entry
+// Bs, row part of stage k: the right-hand sides of the two corrections to the affine step (the corrector and
+// the centring-only step solve the affine step's system with other complementarity targets, so each is the
+// affine step plus the solution for the difference of the right-hand sides: no stationarity residual, no
+// dynamics residual, no initial-state defect)
 template <int NH, int KIND, bool RC = false>
 DEV void stage_Bs_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, double sigma_mu, const BsIn<NH> &in,
                           BsOut &out, const KR &kr = KR{false, false})
@@ -1697,7 +1695,7 @@ DEV void stage_Bs_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, d
     const double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
                  (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
 #pragma unroll
-    for (int j = 0; j < NZ; ++j) gt2[j] = gt1[j];
+    for (int j = 0; j < NZ; ++j) { gt1[j] = 0.0; gt2[j] = 0.0; }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
         if (!row_present<KIND>(r)) continue;
@@ -1711,15 +1709,14 @@ DEV void stage_Bs_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, d
         double rdu = (jv - dup) + tu[r];
         double til = (MPCX_STORE_RECIP || RC) ? til_[r] : 1.0 / tl[r], tiu = (MPCX_STORE_RECIP || RC) ? tiu_[r] : 1.0 / tu[r];
         double jda = jdot(r, jx, jy, dva);
-        // complementarity targets: corrector and centring-only
+        // what the corrector and the centring-only step add to the affine complementarity targets
         const double ml = ll[r] * tl[r], mu_ = lu[r] * tu[r];
         const double dtla = jda - rdl, dtua = -jda - rdu;
         const double dlla = -(fma(ll[r], dtla, ml) * til);
         const double dlua = -(fma(lu[r], dtua, mu_) * tiu);
-        const double rml1 = fma(dtla, dlla, ml) - sigma_mu, rmu1 = fma(dtua, dlua, mu_) - sigma_mu;
-        const double rml2 = ml - sigma_mu, rmu2 = mu_ - sigma_mu;
-        const double q1 = fma(-ll[r], rdl, rml1) * til - fma(-lu[r], rdu, rmu1) * tiu;
-        const double q2 = fma(-ll[r], rdl, rml2) * til - fma(-lu[r], rdu, rmu2) * tiu;
+        const double cl1 = fma(dtla, dlla, -sigma_mu), cu1 = fma(dtua, dlua, -sigma_mu);
+        const double q1 = cl1 * til - cu1 * tiu;
+        const double q2 = (-sigma_mu) * til - (-sigma_mu) * tiu;
         if (r < ROW_G0) { gt1[r] = pr ? gt1[r] + q1 : gt1[r]; gt2[r] = pr ? gt2[r] + q2 : gt2[r]; }
         else {
             gt1[2] = pr ? fma(jx, q1, gt1[2]) : gt1[2];
@@ -1757,7 +1754,7 @@ DEV void stage_Bs_rec(const Lane &L, const BsOut &in, const double *pi1, const d
             const double *gt = sidx ? in.gt2 : in.gt1;
             double w[NX], m[NZ];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) w[i] = pin[i] + in.prb[i];
+            for (int i = 0; i < NX; ++i) w[i] = pin[i];
 #pragma unroll
             for (int j = 0; j < NZ; ++j) m[j] = gt[j];
             add_BAt(L, in.ab, w, m);
@@ -1904,7 +1901,7 @@ DEV void stage_F_load(const Lane &L, int k, FIn<NH, NS> &in, const KR &kr = KR{f
         load_ab<NH, KIND>(L, k, ab);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            rb[i] = ldw<KIND>(L, k, M::RB + i);
+            rb[i] = (NS == 1) ? ldw<KIND>(L, k, M::RB + i) : 0.0;      // (the corrections have no dynamics residual)
             kg[0][i] = ldw<KIND>(L, k, M::K + i);
             kg[1][i] = ldw<KIND>(L, k, M::K + NX + i);
         }
@@ -1939,6 +1936,10 @@ DEV void stage_F_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, in
             F_rec(L, ab, kg, kv[q], rb, dx[q], dvk[q], dxn[q]);
             dvk[q][0] = is_last<KIND>(kr) ? 0.0 : dvk[q][0];
             dvk[q][1] = is_last<KIND>(kr) ? 0.0 : dvk[q][1];
+        }
+        if (NS == 2) {      // the step = the affine step + the correction just formed (dx[q] carries the correction)
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) dvk[q][j] = dva[j] + dvk[q][j];
         }
 #pragma unroll
         for (int j = 0; j < NZ; ++j) {
@@ -2752,10 +2753,10 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             BsIn<NH> bin = {};
             BsOut t2 = {};
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { bin.x[i] = R.x[i]; t2.prb[i] = ro.prb[i]; t2.k0[i] = ro.K[0][i]; t2.k1[i] = ro.K[1][i]; }
+            for (int i = 0; i < NX; ++i) { bin.x[i] = R.x[i]; t2.k0[i] = ro.K[0][i]; t2.k1[i] = ro.K[1][i]; }
             bin.u[0] = R.u[0]; bin.u[1] = R.u[1];
 #pragma unroll
-            for (int jj = 0; jj < NZ; ++jj) { bin.v[jj] = R.v[jj]; bin.dva[jj] = R.dva[jj]; t2.gt1[jj] = t.rg[jj]; }
+            for (int jj = 0; jj < NZ; ++jj) { bin.v[jj] = R.v[jj]; bin.dva[jj] = R.dva[jj]; }
 #pragma unroll
             for (int r = 0; r < M::R; ++r) {
                 bin.ll[r] = R.ll[r]; bin.lu[r] = R.lu[r]; bin.tl[r] = R.tl[r]; bin.tu[r] = R.tu[r];
@@ -2769,7 +2770,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             if (kj == N) stage_Bs_rec<LAST>(S, t2, o1, o2, o1, o2, kvo);
             fresh_ab(t2.ab);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { t2.prb[i] = fresh(t2.prb[i]); t2.k0[i] = fresh(t2.k0[i]); t2.k1[i] = fresh(t2.k1[i]); }
+            for (int i = 0; i < NX; ++i) { t2.k0[i] = fresh(t2.k0[i]); t2.k1[i] = fresh(t2.k1[i]); }
 #pragma unroll
             for (int jj = 0; jj < NZ; ++jj) { t2.gt1[jj] = fresh(t2.gt1[jj]); t2.gt2[jj] = fresh(t2.gt2[jj]); }
             t2.l10 = fresh(t2.l10);
@@ -2795,7 +2796,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             FIn<NH, 2> ld = {};
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                ld.x[i] = R.x[i]; ld.rb[i] = t.rb[i]; ld.kg[0][i] = ro.K[0][i]; ld.kg[1][i] = ro.K[1][i];
+                ld.x[i] = R.x[i]; ld.rb[i] = 0.0; ld.kg[0][i] = ro.K[0][i]; ld.kg[1][i] = ro.K[1][i];
             }
             ld.u[0] = R.u[0]; ld.u[1] = R.u[1];
             ld.kv[0][0] = kvo[0][0]; ld.kv[0][1] = kvo[0][1]; ld.kv[1][0] = kvo[1][0]; ld.kv[1][1] = kvo[1][1];
@@ -2872,7 +2873,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             stw<ANY>(S, 0, M::QPI + i, R.qpi[i]);
-            stw<ANY>(S, 0, M::RG + NU + i, R.rgo[i]);
+            stw<ANY>(S, 0, M::RG + i, R.rgo[i]);
         }
 #pragma unroll
         for (int r = 0; r < M::R; ++r) {
@@ -3274,7 +3275,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
             // [stage][field][lane] layout every word of a problem sits in a cache line of its own, so a
             // word not copied is a line not fetched.
             for (int part = 0; part < 2; ++part) {
-                const int lo = part ? M::DV : M::X, hi = part ? M::F : M::RG + NZ;
+                const int lo = part ? M::DV : M::X, hi = part ? M::F : M::RG + NX;
                 for (int f0 = lo; f0 < hi; f0 += 16) {
                     double tmp[16];
 #pragma unroll

@@ -181,6 +181,8 @@ typedef struct {
     /* Newton system */
     real Ht[NZ], hxx, hxy, hyy;        /* barrier Hessian: diagonal + (x,y) block */
     real gt[NZ];
+    real gd[NZ];                        /* right-hand side of the correction to the affine step */
+    real pa[NX];                        /* p of the affine solve (study switch only) */
     real K[NU][NX], kv[NU], l10, d0, d1;   /* d0, d1: RECIPROCALS of the pivots of M_uu */
     real P[NX][NX], p[NX];             /* full symmetric storage */
     real dv[NZ], dpi[NX];
@@ -571,22 +573,36 @@ static void qp_build_rhs(const problem *pb, stage *st, int mode, real sigma_mu)
             for (int j = 0; j < NZ; ++j) s->Ht[j] = s->Hd[j];
             s->hxx = s->hxy = s->hyy = (real)0.0;
         }
-        for (int j = 0; j < NZ; ++j) s->gt[j] = s->rg[j];
+        for (int j = 0; j < NZ; ++j) { s->gt[j] = s->rg[j]; s->gd[j] = (real)0.0; }
         for (int r = s->r0; r < s->r1; ++r) {
             if (!((s->rmask >> r) & 1u)) continue;
             real til = (real)1.0 / s->t_l[r], tiu = (real)1.0 / s->t_u[r];
             real rml = s->lam_l[r] * s->t_l[r], rmu = s->lam_u[r] * s->t_u[r];
+            /* cl, cu: what modes 1 and 2 add to the affine complementarity targets */
+            real cl = (real)0.0, cu = (real)0.0;
             if (mode == 1) {
                 real jd = row_dot(s, r, s->dva);
                 real dtl = jd - s->rd_l[r];
                 real dtu = -jd - s->rd_u[r];
                 real dll = -(rfma(s->lam_l[r], dtl, rml) * til);
                 real dlu = -(rfma(s->lam_u[r], dtu, rmu) * tiu);
+                cl = rfma(dtl, dll, -sigma_mu);
+                cu = rfma(dtu, dlu, -sigma_mu);
                 rml = rfma(dtl, dll, rml) - sigma_mu;
                 rmu = rfma(dtu, dlu, rmu) - sigma_mu;
             } else if (mode == 2) {
+                cl = -sigma_mu;
+                cu = -sigma_mu;
                 rml = rml - sigma_mu;
                 rmu = rmu - sigma_mu;
+            }
+            if (mode != 0) {
+                real qd = cl * til - cu * tiu;
+                if (r < ROW_G0) s->gd[r] = s->gd[r] + qd;
+                else {
+                    s->gd[2] = rfma(s->jx[r], qd, s->gd[2]);
+                    s->gd[3] = rfma(s->jy[r], qd, s->gd[3]);
+                }
             }
             real ql = rfma(-s->lam_l[r], s->rd_l[r], rml) * til;
             real qu = rfma(-s->lam_u[r], s->rd_u[r], rmu) * tiu;
@@ -677,21 +693,28 @@ static void riccati_factor(const problem *pb, stage *st)
 
 static int g_dpi_costate = 0;     /* MPCX_ORACLE_DPI_COSTATE, see riccati_solve() */
 /* backward + forward substitution with the stored factors; result in dv, dpi */
-static void riccati_solve(const problem *pb, stage *st)
+static void riccati_solve(const problem *pb, stage *st, int delta)
 {
+    /* delta = 0: the affine step, full right-hand side gt and dynamics residual rb.
+     * delta = 1: the corrector (or centring-only) step as the affine step plus a correction: the two
+     * systems differ in the right-hand side of the rows only, so the correction solves the same system
+     * with right-hand side gd, no dynamics residual and no initial-state defect, and dv = dva + it.
+     * (Equal to solving with the full right-hand side in exact arithmetic; this form needs neither the
+     * stationarity residual nor P rb nor rb in the second pair of sweeps.) */
     const int N = pb->N;
-    for (int i = 0; i < NX; ++i) st[N].p[i] = st[N].gt[NU + i];
+    for (int i = 0; i < NX; ++i) st[N].p[i] = delta ? st[N].gd[NU + i] : st[N].gt[NU + i];
     for (int k = N - 1; k >= 0; --k) {
         stage *s = &st[k];
         const stage *n = &st[k + 1];
         real w[NX], m[NZ];
         for (int i = 0; i < NX; ++i) {
+            if (delta) { w[i] = n->p[i]; continue; }
             real acc = n->P[i][0] * s->rb[0];
             for (int j = 1; j < NX; ++j) acc = rfma(n->P[i][j], s->rb[j], acc);
             w[i] = n->p[i] + acc;
         }
         for (int c = 0; c < NZ; ++c) {
-            real acc = s->gt[c];
+            real acc = delta ? s->gd[c] : s->gt[c];
             for (int i = 0; i < NX; ++i)
                 acc = rfma((c < NU) ? s->B[i][c] : s->A[i][c - NU], w[i], acc);
             m[c] = acc;
@@ -717,20 +740,27 @@ static void riccati_solve(const problem *pb, stage *st)
             s->dv[c] = acc;
         }
         for (int i = 0; i < NX; ++i) {
-            real acc = s->rb[i];
+            real acc = delta ? (real)0.0 : s->rb[i];
             for (int j = 0; j < NX; ++j) acc = rfma(s->A[i][j], s->dv[NU + j], acc);
             for (int c = 0; c < NU; ++c) acc = rfma(s->B[i][c], s->dv[c], acc);
             n->dv[NU + i] = acc;
         }
     }
     st[N].dv[0] = st[N].dv[1] = (real)0.0;
+    if (delta) {
+        for (int k = 0; k <= N; ++k)
+            for (int j = 0; j < NZ; ++j) st[k].dv[j] = st[k].dva[j] + st[k].dv[j];
+    } else {
+        for (int k = 0; k <= N; ++k)
+            for (int i = 0; i < NX; ++i) st[k].pa[i] = st[k].p[i];
+    }
     if (g_dpi_costate) {
         /* study switch (MPCX_ORACLE_DPI_COSTATE=1; never set by the product or the parity tests): the
          * form HPIPM uses, dpi_k = P_k dx_k + p_k */
         for (int k = 1; k <= N; ++k) {
             stage *n = &st[k];
             for (int i = 0; i < NX; ++i) {
-                real acc = n->p[i];
+                real acc = delta ? n->pa[i] + n->p[i] : n->p[i];
                 for (int j = 0; j < NX; ++j) acc = rfma(n->P[i][j], n->dv[NU + j], acc);
                 n->dpi[i] = acc;
             }
@@ -873,7 +903,7 @@ static int qp_solve(const problem *pb, const mpcx_opts *o, stage *st, int *iters
         /* predictor */
         qp_build_rhs(pb, st, 0, (real)0.0);
         riccati_factor(pb, st);
-        riccati_solve(pb, st);
+        riccati_solve(pb, st, 0);
         real S1, S2;
         real a_aff = qp_step_length(pb, st, 0, (real)0.0, &S1, &S2);
         real S0 = R.mu * (real)(double)m_total;
@@ -887,12 +917,12 @@ static int qp_solve(const problem *pb, const mpcx_opts *o, stage *st, int *iters
         /* corrector */
         int mode = 1;
         qp_build_rhs(pb, st, 1, sigma_mu);
-        riccati_solve(pb, st);
+        riccati_solve(pb, st, 1);
         real alpha = qp_step_length(pb, st, 1, sigma_mu, NULL, NULL);
         if (o->cond_pred_corr && alpha < a_aff) {
             mode = 2;
             qp_build_rhs(pb, st, 2, sigma_mu);
-            riccati_solve(pb, st);
+            riccati_solve(pb, st, 1);
             alpha = qp_step_length(pb, st, 2, sigma_mu, NULL, NULL);
         }
         if (g_debug)

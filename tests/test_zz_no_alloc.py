@@ -57,8 +57,8 @@ def test_static_scratch_entry_point_matches_device_entry_point():
         cases.assert_same_solution(got, want, f"static scratch, B={packed.B} N={packed.N}")
         assert (got["status"] >= 0).all() and (want["status"] == 0).any()
     # a horizon whose single-wavefront workspace exceeds the built-in scratch is refused, nothing is launched
-    big = synthetic_batch(2, duration=80.0)
-    assert big.N == 800
+    big = synthetic_batch(2, duration=200.0)
+    assert big.N == 2000
     dev = torch.device("cuda", 0)
     d_pd = torch.from_numpy(big.pdata).to(dev)
     d_no = torch.from_numpy(big.n_obs).to(dev)
