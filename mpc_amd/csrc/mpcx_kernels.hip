@@ -92,7 +92,9 @@ struct Map {
     static constexpr int RB = RG + 5;          // 5  dynamics residual
     static constexpr int K = RB + 5;           // 10 feedback gain, row-major [2][5]
     static constexpr int LDL = K + 10;         // 3  l10, 1/d0, 1/d1 of the LDL' of M_uu
-    static constexpr int KV = LDL + 3;         // 2  feed-forward
+    static constexpr int GA = LDL + 3;         // 7  rows' part of the corrections' right-hand sides: the corrector term ...
+    static constexpr int GB = GA + 7;          // 7  ... and what sigma*mu multiplies (left by the affine forward sweep)
+    static constexpr int KV = GB + 7;          // 2  feed-forward
     static constexpr int DV = KV + 2;          // 7  step
     static constexpr int DVA = DV + 7;         // 7  affine (predictor) step
     // the centring-only solution, computed alongside the corrector one; same order and
@@ -1628,40 +1630,21 @@ struct BsOut {
     AB ab;
 };
 
-// what the row part of Bs reads of a stage besides the factors that go straight into BsOut
-template <int NH>
+// what Bs reads of a stage besides the factors that go straight into BsOut: the two per-variable sums the
+// affine forward sweep left (stage_F_compute, NS = 1)
 struct BsIn {
-    double x[NX], u[NU], v[NZ], dva[NZ];
-    double ll[Map<NH>::R], lu[Map<NH>::R], tl[Map<NH>::R], tu[Map<NH>::R], til_[Map<NH>::R], tiu_[Map<NH>::R];
+    double ga[NZ], gb[NZ];
 };
 
-// Bs, loads of stage k: the iterate and the affine step (in), the stationarity residual (out.gt1)
-// and the stored factors of the stage (out)
+// Bs, loads of stage k: the two sums (in) and the stored factors of the stage (out)
 template <int NH, int KIND>
-DEV void stage_Bs_load(const Lane &L, int k, BsIn<NH> &in, BsOut &out, const KR &kr = KR{false, false})
+DEV void stage_Bs_load(const Lane &L, int k, BsIn &in, BsOut &out, const KR &kr = KR{false, false})
 {
     typedef Map<NH> M;
-    double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&dva)[NZ] = in.dva;
-    double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
-           (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
-    load_xu<NH, KIND>(L, k, kr, x, u);
 #pragma unroll
     for (int j = 0; j < NZ; ++j) {
-        v[j] = ldw<KIND>(L, k, M::V + j);
-        dva[j] = ldw<KIND>(L, k, M::DVA + j);
-    }
-#pragma unroll
-    for (int r = 0; r < M::R; ++r) {
-        ll[r] = lu[r] = tl[r] = tu[r] = til_[r] = tiu_[r] = 1.0;
-        if (!row_present<KIND>(r)) continue;
-        ll[r] = ldw<KIND>(L, k, M::LAML + r);
-        lu[r] = ldw<KIND>(L, k, M::LAMU + r);
-        tl[r] = ldw<KIND>(L, k, M::TL + r);
-        tu[r] = ldw<KIND>(L, k, M::TU + r);
-        if (MPCX_STORE_RECIP) {
-            til_[r] = ldw<KIND>(L, k, M::TIL + r);
-            tiu_[r] = ldw<KIND>(L, k, M::TIU + r);
-        }
+        in.ga[j] = ldw<KIND>(L, k, M::GA + j);
+        in.gb[j] = ldw<KIND>(L, k, M::GB + j);
     }
     out.ab = AB{};
     out.l10 = 0.0; out.d0 = 1.0; out.d1 = 1.0;
@@ -1681,59 +1664,67 @@ DEV void stage_Bs_load(const Lane &L, int k, BsIn<NH> &in, BsOut &out, const KR 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Bs, row part of stage k: the right-hand sides of the two corrections to the affine step (the corrector and
-// the centring-only step solve the affine step's system with other complementarity targets, so each is the
-// affine step plus the solution for the difference of the right-hand sides: no stationarity residual, no
-// dynamics residual, no initial-state defect)
-template <int NH, int KIND, bool RC = false>
-DEV void stage_Bs_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, double sigma_mu, const BsIn<NH> &in,
-                          BsOut &out, const KR &kr = KR{false, false})
+// Bs, right-hand sides of the two corrections to the affine step.  The corrector and the centring-only step
+// solve the affine step's system with other complementarity targets, so each is the affine step plus the
+// solution for the difference of the right-hand sides (no stationarity residual, no dynamics residual, no
+// initial-state defect).  That difference is the rows' J' (c_l / t_l - c_u / t_u) with c = dt_a dlam_a -
+// sigma*mu (corrector) or -sigma*mu (centring only): ga - sigma*mu gb and -sigma*mu gb.
+DEV void stage_Bs_compute(double sigma_mu, const BsIn &in, BsOut &out)
+{
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) {
+        out.gt1[j] = fma(-sigma_mu, in.gb[j], in.ga[j]);
+        out.gt2[j] = (-sigma_mu) * in.gb[j];
+    }
+}
+
+// The two sums formed from a stage resident in registers (the bursts, which would otherwise have to carry
+// them from the affine forward sweep to here): the operations of stage_F_compute (NS = 1), on the affine
+// step dva.  in.til_ / in.tiu_ hold the reciprocals of the slacks.
+template <int NH, int KIND>
+DEV void stage_Bs_sums(const Lane &L, const PC<NH> &pc, const B0In<NH> &in, BsIn &sums, const KR &kr)
 {
     typedef Map<NH> M;
-    const double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&dva)[NZ] = in.dva;
-    double *gt1 = out.gt1, *gt2 = out.gt2;
-    const double (&ll)[M::R] = in.ll, (&lu)[M::R] = in.lu, (&tl)[M::R] = in.tl, (&tu)[M::R] = in.tu,
-                 (&til_)[M::R] = in.til_, (&tiu_)[M::R] = in.tiu_;
+    double (&ga)[NZ] = sums.ga, (&gb)[NZ] = sums.gb;
 #pragma unroll
-    for (int j = 0; j < NZ; ++j) { gt1[j] = 0.0; gt2[j] = 0.0; }
+    for (int j = 0; j < NZ; ++j) { ga[j] = 0.0; gb[j] = 0.0; }
 #pragma unroll
     for (int r = 0; r < M::R; ++r) {
         if (!row_present<KIND>(r)) continue;
         const bool pr = row_on<KIND>(kr, r) && ((r < 9) || (r - 9 < L.nobs));
         double c, jx, jy, lo, up;
-        row_geom<NH>(pc, r, x, u, c, jx, jy);
+        row_geom<NH>(pc, r, in.x, in.u, c, jx, jy);
         row_bounds<NH, KIND>(L, pc, kr, r, lo, up);
         const double dlo = lo - c, dup = up - c;
-        double jv = jdot(r, jx, jy, v);
-        double rdl = (dlo - jv) + tl[r];
-        double rdu = (jv - dup) + tu[r];
-        double til = (MPCX_STORE_RECIP || RC) ? til_[r] : 1.0 / tl[r], tiu = (MPCX_STORE_RECIP || RC) ? tiu_[r] : 1.0 / tu[r];
-        double jda = jdot(r, jx, jy, dva);
-        // what the corrector and the centring-only step add to the affine complementarity targets
-        const double ml = ll[r] * tl[r], mu_ = lu[r] * tu[r];
-        const double dtla = jda - rdl, dtua = -jda - rdu;
-        const double dlla = -(fma(ll[r], dtla, ml) * til);
-        const double dlua = -(fma(lu[r], dtua, mu_) * tiu);
-        const double cl1 = fma(dtla, dlla, -sigma_mu), cu1 = fma(dtua, dlua, -sigma_mu);
-        const double q1 = cl1 * til - cu1 * tiu;
-        const double q2 = (-sigma_mu) * til - (-sigma_mu) * tiu;
-        if (r < ROW_G0) { gt1[r] = pr ? gt1[r] + q1 : gt1[r]; gt2[r] = pr ? gt2[r] + q2 : gt2[r]; }
-        else {
-            gt1[2] = pr ? fma(jx, q1, gt1[2]) : gt1[2];
-            gt1[3] = pr ? fma(jy, q1, gt1[3]) : gt1[3];
-            gt2[2] = pr ? fma(jx, q2, gt2[2]) : gt2[2];
-            gt2[3] = pr ? fma(jy, q2, gt2[3]) : gt2[3];
+        const double jv = jdot(r, jx, jy, in.v);
+        const double rdl = (dlo - jv) + in.tl[r];
+        const double rdu = (jv - dup) + in.tu[r];
+        const double til = in.til_[r], tiu = in.tiu_[r];
+        const double ml = in.ll[r] * in.tl[r], mu_ = in.lu[r] * in.tu[r];
+        const double jd = jdot(r, jx, jy, in.dva);
+        const double dtl = jd - rdl, dtu = -jd - rdu;
+        const double dll = -(fma(in.ll[r], dtl, ml) * til);
+        const double dlu = -(fma(in.lu[r], dtu, mu_) * tiu);
+        const double ar = (dtl * dll) * til - (dtu * dlu) * tiu;
+        const double br = til - tiu;
+        if (r < ROW_G0) {
+            ga[r] = pr ? ga[r] + ar : ga[r];
+            gb[r] = pr ? gb[r] + br : gb[r];
+        } else {
+            ga[2] = pr ? fma(jx, ar, ga[2]) : ga[2];
+            ga[3] = pr ? fma(jy, ar, ga[3]) : ga[3];
+            gb[2] = pr ? fma(jx, br, gb[2]) : gb[2];
+            gb[3] = pr ? fma(jy, br, gb[3]) : gb[3];
         }
     }
 }
 
 template <int NH, int KIND>
-DEV void stage_Bs_rows(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu, BsOut &out,
-                       const KR &kr = KR{false, false})
+DEV void stage_Bs_rows(const Lane &L, int k, double sigma_mu, BsOut &out, const KR &kr = KR{false, false})
 {
-    BsIn<NH> in;
+    BsIn in;
     stage_Bs_load<NH, KIND>(L, k, in, out, kr);
-    stage_Bs_compute<NH, KIND>(L, o, pc, sigma_mu, in, out, kr);
+    stage_Bs_compute(sigma_mu, in, out);
 }
 
 // Bs, recursion part of a stage: pn1 / pn2 hold p(k+1) of the two systems on entry, p(k) on
@@ -1781,7 +1772,7 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, do
                   double *pn1, double *pn2)
 {
     BsOut t;
-    stage_Bs_rows<NH, KIND>(L, o, pc, k, sigma_mu, t);
+    stage_Bs_rows<NH, KIND>(L, k, sigma_mu, t);
     double kvo[2][NU];
     stage_Bs_rec<KIND>(L, t, pn1, pn2, pn1, pn2, kvo);
     store_rec<NH, KIND>(L, k, KIND != LAST, kvo);
@@ -1914,11 +1905,12 @@ DEV void stage_F_load(const Lane &L, int k, FIn<NH, NS> &in, const KR &kr = KR{f
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// ST = false: nothing is stored; the steps of the stage come back in dvo[q][0..6]
-template <int NH, int KIND, int NS, bool ST = true, bool RC = false>
+// ST = false: nothing is stored; the steps of the stage come back in dvo[q][0..6] and (NS = 1) the two
+// sums for sweep Bs in gao, gbo
+template <int NH, int KIND, int NS, bool ST = true, bool RC = false, bool SUMS = true>
 DEV void stage_F_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, double sigma_mu,
                          FIn<NH, NS> &in, double (*dx)[NX], FAcc &a, const KR &kr = KR{false, false},
-                         double (*dvo)[NZ] = nullptr)
+                         double (*dvo)[NZ] = nullptr, double *gao = nullptr, double *gbo = nullptr)
 {
     typedef Map<NH> M;
     double (&x)[NX] = in.x, (&u)[NU] = in.u, (&v)[NZ] = in.v, (&dva)[NZ] = in.dva;
@@ -1947,7 +1939,9 @@ DEV void stage_F_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, in
             else dvo[q][j] = dvk[q][j];
         }
     }
-    double s1k = 0.0, s2k = 0.0, knum[NS], kden[NS];
+    double s1k = 0.0, s2k = 0.0, knum[NS], kden[NS], ga[NZ], gb[NZ];
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) { ga[j] = 0.0; gb[j] = 0.0; }
 #pragma unroll
     for (int q = 0; q < NS; ++q) { knum[q] = 1.0; kden[q] = 1.0; }
 #pragma unroll
@@ -1999,10 +1993,34 @@ DEV void stage_F_compute(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, in
                 s2 = fma(dtu, dlu, s2);
                 s1k = pr ? s1 : s1k;
                 s2k = pr ? s2 : s2k;
+                // the rows' part of the right-hand sides of the corrections Bs solves for, per variable,
+                // up to the factor sigma*mu that is only known once this sweep has ended
+                // (SUMS = false: the caller forms them later, stage_Bs_sums)
+                if (!SUMS) continue;
+                const double ar = (dtl * dll) * til - (dtu * dlu) * tiu;
+                const double br = til - tiu;
+                if (r < ROW_G0) {
+                    ga[r] = pr ? ga[r] + ar : ga[r];
+                    gb[r] = pr ? gb[r] + br : gb[r];
+                } else {
+                    ga[2] = pr ? fma(jx, ar, ga[2]) : ga[2];
+                    ga[3] = pr ? fma(jy, ar, ga[3]) : ga[3];
+                    gb[2] = pr ? fma(jx, br, gb[2]) : gb[2];
+                    gb[3] = pr ? fma(jy, br, gb[3]) : gb[3];
+                }
             }
         }
     }
-    if (NS == 1) { a.s1 = a.s1 + s1k; a.s2 = a.s2 + s2k; }
+    if (NS == 1) {
+        a.s1 = a.s1 + s1k; a.s2 = a.s2 + s2k;
+        if (SUMS) {
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) {
+                if (ST) { stw<KIND>(L, k, M::GA + j, ga[j]); stw<KIND>(L, k, M::GB + j, gb[j]); }
+                else { gao[j] = ga[j]; gbo[j] = gb[j]; }
+            }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
         const double ak = knum[q] / kden[q];       // longest step of this stage; the step is the min over stages
@@ -2430,8 +2448,7 @@ template <int NH, bool ONE>
 __device__ __attribute__((noinline)) void coop_Bs(COOP_PARAMS, const mpcx_opts *op, double sigma_mu)
 {
     COOP_UNPACK(NH);
-    const mpcx_opts ol = opts_in_registers(op);
-    const mpcx_opts &o = ol;
+    (void)op;
     const int N = __builtin_amdgcn_readfirstlane(C.N);      // (the same in every lane: loop counts in scalar registers)
     const int j = (int)threadIdx.x;
     double c1[NX], c2[NX];          // p of the lowest stage of the block above, both systems
@@ -2443,7 +2460,7 @@ __device__ __attribute__((noinline)) void coop_Bs(COOP_PARAMS, const mpcx_opts *
         BsOut t = {};
         const KR kr = {kj == 0, kj == N};
         SUB_BEGIN();
-        if (kj <= N) stage_Bs_rows<NH, ANY>(S, o, pc, 0, sigma_mu, t, kr);
+        if (kj <= N) stage_Bs_rows<NH, ANY>(S, 0, sigma_mu, t, kr);
         SUB_END(24);
         double o1[NX], o2[NX], kvo[2][NU] = {{0.0, 0.0}, {0.0, 0.0}};
 #pragma unroll
@@ -2725,7 +2742,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
             double dvo[1][NZ];
 #pragma unroll
             for (int jj = 0; jj < NZ; ++jj) dvo[0][jj] = 0.0;
-            if (on) stage_F_compute<NH, ANY, 1, false, true>(S, o, pc, 0, 0.0, ld, dxi, a, kr, dvo);
+            if (on) stage_F_compute<NH, ANY, 1, false, true, false>(S, o, pc, 0, 0.0, ld, dxi, a, kr, dvo);
 #pragma unroll
             for (int jj = 0; jj < NZ; ++jj) R.dva[jj] = dvo[0][jj];
             a_aff = uniform(wave_min(a.alpha[0]));
@@ -2750,21 +2767,16 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
         // ================= Bs: corrector and centring-only right-hand sides, substituted backwards =================
         double o1[NX], o2[NX], kvo[2][NU] = {{0.0, 0.0}, {0.0, 0.0}};
         {
-            BsIn<NH> bin = {};
+            BsIn bin;
             BsOut t2 = {};
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { bin.x[i] = R.x[i]; t2.k0[i] = ro.K[0][i]; t2.k1[i] = ro.K[1][i]; }
-            bin.u[0] = R.u[0]; bin.u[1] = R.u[1];
+            for (int i = 0; i < NX; ++i) { t2.k0[i] = ro.K[0][i]; t2.k1[i] = ro.K[1][i]; }
 #pragma unroll
-            for (int jj = 0; jj < NZ; ++jj) { bin.v[jj] = R.v[jj]; bin.dva[jj] = R.dva[jj]; }
-#pragma unroll
-            for (int r = 0; r < M::R; ++r) {
-                bin.ll[r] = R.ll[r]; bin.lu[r] = R.lu[r]; bin.tl[r] = R.tl[r]; bin.tu[r] = R.tu[r];
-                bin.til_[r] = R.til_[r]; bin.tiu_[r] = R.tiu_[r];
-            }
+            for (int jj = 0; jj < NZ; ++jj) { bin.ga[jj] = 0.0; bin.gb[jj] = 0.0; }
+            if (on) stage_Bs_sums<NH, ANY>(S, pc, R, bin, kr);
             t2.ab = R.ab;
             t2.l10 = (kj < N) ? ro.l10 : 0.0; t2.d0 = (kj < N) ? ro.d0 : 1.0; t2.d1 = (kj < N) ? ro.d1 : 1.0;
-            if (on) stage_Bs_compute<NH, ANY, true>(S, o, pc, sigma_mu, bin, t2, kr);
+            stage_Bs_compute(sigma_mu, bin, t2);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { o1[i] = 0.0; o2[i] = 0.0; }
             if (kj == N) stage_Bs_rec<LAST>(S, t2, o1, o2, o1, o2, kvo);

@@ -182,6 +182,7 @@ typedef struct {
     real Ht[NZ], hxx, hxy, hyy;        /* barrier Hessian: diagonal + (x,y) block */
     real gt[NZ];
     real gd[NZ];                        /* right-hand side of the correction to the affine step */
+    real ga[NZ], gb[NZ];                /* its two parts: gd = ga - sigma*mu * gb (corrector), -sigma*mu * gb (centring) */
     real pa[NX];                        /* p of the affine solve (study switch only) */
     real K[NU][NX], kv[NU], l10, d0, d1;   /* d0, d1: RECIPROCALS of the pivots of M_uu */
     real P[NX][NX], p[NX];             /* full symmetric storage */
@@ -573,36 +574,27 @@ static void qp_build_rhs(const problem *pb, stage *st, int mode, real sigma_mu)
             for (int j = 0; j < NZ; ++j) s->Ht[j] = s->Hd[j];
             s->hxx = s->hxy = s->hyy = (real)0.0;
         }
-        for (int j = 0; j < NZ; ++j) { s->gt[j] = s->rg[j]; s->gd[j] = (real)0.0; }
+        for (int j = 0; j < NZ; ++j) {
+            s->gt[j] = s->rg[j];
+            /* what modes 1 and 2 add to the affine right-hand side, from the two sums the affine
+             * step-length pass left per variable (qp_step_length) */
+            if (mode != 0) s->gd[j] = (mode == 1) ? rfma(-sigma_mu, s->gb[j], s->ga[j]) : (-sigma_mu) * s->gb[j];
+        }
         for (int r = s->r0; r < s->r1; ++r) {
             if (!((s->rmask >> r) & 1u)) continue;
             real til = (real)1.0 / s->t_l[r], tiu = (real)1.0 / s->t_u[r];
             real rml = s->lam_l[r] * s->t_l[r], rmu = s->lam_u[r] * s->t_u[r];
-            /* cl, cu: what modes 1 and 2 add to the affine complementarity targets */
-            real cl = (real)0.0, cu = (real)0.0;
             if (mode == 1) {
                 real jd = row_dot(s, r, s->dva);
                 real dtl = jd - s->rd_l[r];
                 real dtu = -jd - s->rd_u[r];
                 real dll = -(rfma(s->lam_l[r], dtl, rml) * til);
                 real dlu = -(rfma(s->lam_u[r], dtu, rmu) * tiu);
-                cl = rfma(dtl, dll, -sigma_mu);
-                cu = rfma(dtu, dlu, -sigma_mu);
                 rml = rfma(dtl, dll, rml) - sigma_mu;
                 rmu = rfma(dtu, dlu, rmu) - sigma_mu;
             } else if (mode == 2) {
-                cl = -sigma_mu;
-                cu = -sigma_mu;
                 rml = rml - sigma_mu;
                 rmu = rmu - sigma_mu;
-            }
-            if (mode != 0) {
-                real qd = cl * til - cu * tiu;
-                if (r < ROW_G0) s->gd[r] = s->gd[r] + qd;
-                else {
-                    s->gd[2] = rfma(s->jx[r], qd, s->gd[2]);
-                    s->gd[3] = rfma(s->jy[r], qd, s->gd[3]);
-                }
             }
             real ql = rfma(-s->lam_l[r], s->rd_l[r], rml) * til;
             real qu = rfma(-s->lam_u[r], s->rd_u[r], rmu) * tiu;
@@ -801,6 +793,8 @@ static real qp_step_length(const problem *pb, stage *st, int mode, real sigma_mu
         stage *s = &st[k];
         real num = 1.0, den = 1.0;    /* smallest ratio of this stage; the step is the min over stages */
         real s1k = 0.0, s2k = 0.0;    /* sums of this stage, then added to the totals */
+        if (mode == 0)
+            for (int j = 0; j < NZ; ++j) { s->ga[j] = (real)0.0; s->gb[j] = (real)0.0; }
         for (int r = s->r0; r < s->r1; ++r) {
             if (!((s->rmask >> r) & 1u)) continue;
             real til = (real)1.0 / s->t_l[r], tiu = (real)1.0 / s->t_u[r];
@@ -832,6 +826,20 @@ static real qp_step_length(const problem *pb, stage *st, int mode, real sigma_mu
             s1k = rfma(s->t_u[r], dlu, s1k);
             s2k = rfma(dtl, dll, s2k);
             s2k = rfma(dtu, dlu, s2k);
+            if (mode == 0) {
+                /* the rows' part of the corrector's and the centring step's right-hand sides, up to the
+                 * factor sigma*mu that is known only after this pass:
+                 *   ga = J' ((dt_a dlam_a)_l / t_l - (dt_a dlam_a)_u / t_u),  gb = J' (1 / t_l - 1 / t_u) */
+                real ar = (dtl * dll) * til - (dtu * dlu) * tiu;
+                real br = til - tiu;
+                if (r < ROW_G0) { s->ga[r] = s->ga[r] + ar; s->gb[r] = s->gb[r] + br; }
+                else {
+                    s->ga[2] = rfma(s->jx[r], ar, s->ga[2]);
+                    s->ga[3] = rfma(s->jy[r], ar, s->ga[3]);
+                    s->gb[2] = rfma(s->jx[r], br, s->gb[2]);
+                    s->gb[3] = rfma(s->jy[r], br, s->gb[3]);
+                }
+            }
         }
         s1 = s1 + s1k;
         s2 = s2 + s2k;
