@@ -3042,7 +3042,7 @@ template <int NH>
 __global__ void __launch_bounds__(64) __attribute__((disable_tail_calls))
 mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
                 int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots, unsigned deal, int burst_few,
-                double hold_alpha, int hold_extra)
+                double hold_alpha, int hold_extra, int boost_mul)
 {
     const mpcx_opts &o = *op;
     typedef Map<NH> M;
@@ -3628,7 +3628,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *wor
                     if (slots > 0 && L.region == 0) (void)move_to_region(p);
                 }
                 seen |= 1ull << p;
-                int k = best / boost_div;
+                int k = (int)(((long long)best * boost_mul) / boost_div);
                 if (k > budget) k = budget;
                 if (k < 1) k = 1;
                 budget -= k;
@@ -3736,11 +3736,11 @@ size_t mpcx_stage_doubles(int nh)
 hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, const mpcx_result &out,
                            double *workspace, int n_waves, int lanes, int coop_max, int lin_max, int coop_layout, int slots, hipStream_t stream)
 {
-    int boost_min = 16, boost_div = 1, boost_cap = 8192, boost_lanes = 4;
-    if (const char *e = getenv("MPCX_BOOST")) {      // "min,div,cap,lanes"; div 0 switches the extra iterations off
-        int a = 0, b = 0, c = 0, d = 1;
-        if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d) >= 3 && a >= 0 && b >= 0 && c >= 0 && d >= 0) {
-            boost_min = a; boost_div = b; boost_cap = c; boost_lanes = d;
+    int boost_min = 16, boost_div = 1, boost_cap = 8192, boost_lanes = 4, boost_mul = 1;
+    if (const char *e = getenv("MPCX_BOOST")) {      // "min,div,cap,lanes[,mul]"; div 0 switches the extra iterations off
+        int a = 0, b = 0, c = 0, d = 1, m = 1;
+        if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &m) >= 3 && a >= 0 && b >= 0 && c >= 0 && d >= 0 && m >= 1) {
+            boost_min = a; boost_div = b; boost_cap = c; boost_lanes = d; boost_mul = m;
         }
     }
     if (const char *e = getenv("MPCX_SLOTS")) { int v = atoi(e); if (v >= 0 && v <= slots) slots = v; }   // fewer only
@@ -3787,12 +3787,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     }
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul); break;
 #else
     default: return hipErrorInvalidValue;
 #endif
