@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 106
+#define MPCX_VERSION 107
 
 #define MPCX_NX 5       /* state  [x, y, theta, v, delta]        (core_solver.py:131) */
 #define MPCX_NU 2       /* input  [acceleration, steering rate]  (core_solver.py:132) */
@@ -165,13 +165,19 @@ int    mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts,
  * memory on every GPU the library is loaded on; the call makes no hipMalloc / hipFree, no copy from
  * host memory and no other allocating call, and queues its kernels on `stream`.  The first call
  * on a device looks the array's address up (make it outside a graph capture).
- * Limits: the scratch must hold one wavefront's share, which bounds N (N <= 830 or so; larger N
- * returns MPCX_E_BADARG); B is not limited, but only as many wavefronts run as the scratch holds
- * (16 at N = 50), so large batches are slow here.  All calls on one GPU share the array: calls
- * that overlap in time on the same GPU (different streams or threads) race and must not be made.
+ * Limits: the scratch must hold one wavefront's share, which bounds N: N > mpcx_static_max_horizon()
+ * returns MPCX_E_BADARG; B is not limited, but only mpcx_static_max_wavefronts(N) wavefronts run (as
+ * many as the scratch holds), so large batches are slow here.  All calls on one GPU share the array:
+ * calls that overlap in time on the same GPU race and must not be made.  Calls queued on ONE stream run
+ * one after the other and are fine; a call on another stream while the previous call's kernels have
+ * not finished is detected (an event behind each call, queried on entry) and returns MPCX_E_BADARG
+ * without launching.  Calls made under stream capture are not checked: whoever launches the captured
+ * graphs keeps them apart.
  */
 #define MPCX_STATIC_SCRATCH_BYTES (64u << 20)
 int mpcx_solve_batch_static(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *out, void *stream);
+int mpcx_static_max_horizon(void);              /* largest N the built-in scratch holds           */
+int mpcx_static_max_wavefronts(int32_t N);      /* wavefronts it holds at horizon N (0: too long) */
 
 /*
  * Initial state guess of core_solver.py:477-499, computed on the device from the problem table:

@@ -100,6 +100,9 @@ def load_library(path=None):
         lib.mpcx_solve_batch_static.argtypes = [C.POINTER(MpcxBatch), C.POINTER(MpcxOpts),
                                                 C.POINTER(MpcxResult), C.c_void_p]
         lib.mpcx_solve_batch_static.restype = C.c_int
+        lib.mpcx_static_max_horizon.restype = C.c_int
+        lib.mpcx_static_max_wavefronts.argtypes = [C.c_int32]
+        lib.mpcx_static_max_wavefronts.restype = C.c_int
     if path is None:
         _lib = lib
     return lib

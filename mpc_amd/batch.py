@@ -44,7 +44,8 @@ class PackedBatch:
     pdata: np.ndarray    # float64 [NFIELDS, B]
     n_obs: np.ndarray    # int32 [B]
     xguess: np.ndarray   # float64 [N+1, 5, B], or None = the library computes the guess on the
-                         # device from the problem table (obstacle-free problems only)
+                         # device from the problem table (up to MAX_OBS obstacles per problem: the
+                         # reference's rules, last-bit differences in pow and arctan2, see library_guess)
     duration: float = 0.0
     uguess: np.ndarray = None    # float64 [N, 2, B] or None = zeros (the reference's start)
 
@@ -352,7 +353,8 @@ def _ego_fields(ego, N, duration):
     if ego.obstacles is not None and len(ego.obstacles) > 0:
         n_obs = len(ego.obstacles)
         if n_obs > MAX_OBS:
-            raise ValueError(f"at most {MAX_OBS} obstacles per problem, got {n_obs}")
+            raise ValueError(f"this solver takes at most {MAX_OBS} obstacles per problem, got {n_obs} "
+                             f"(a limit of the HIP library, MPCX_MAX_OBS; the reference has none)")
         for j, (ox, oy, orad, margin) in enumerate(ego.obstacles):
             col[F_OBS + 3 * j:F_OBS + 3 * j + 3] = (ox, oy, (orad + margin)**2)
     return col, n_obs, corridor

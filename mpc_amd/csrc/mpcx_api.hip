@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <atomic>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "../../include/mpcx.h"
@@ -24,6 +25,13 @@ namespace {
 
 constexpr int kMaxDevices = 64;
 std::atomic<void *> g_scratch_ptr[kMaxDevices];
+// Overlap guard of mpcx_solve_batch_static, per device: an event recorded behind the last call's
+// kernels and the stream they were queued on.  A call on ANOTHER stream while that event has not
+// completed would share the scratch with a solve in flight and is refused; calls queued on the same
+// stream run one after the other and are fine.  (Calls made under stream capture are neither checked
+// nor recorded: a captured solve runs when its graph is launched, not when it is captured.)
+struct StaticGuard { std::mutex mu; hipEvent_t done = nullptr; hipStream_t last = nullptr; bool have = false; };
+StaticGuard g_guard[kMaxDevices];
 
 thread_local char g_err[512] = "";
 
@@ -239,6 +247,26 @@ int mpcx_max_horizon(void)
 {
     static const int n = mpcx_max_horizon_impl();
     return n;
+}
+
+int mpcx_static_max_horizon(void)
+{
+    static const int n = [] {
+        int lo = 0, hi = 1 << 20;
+        while (lo < hi) {
+            const int mid = lo + (hi - lo + 1) / 2;
+            if (512 + wave_bytes(mid, MPCX_MAX_OBS) <= (size_t)MPCX_STATIC_SCRATCH_BYTES) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    }();
+    return n;
+}
+
+int mpcx_static_max_wavefronts(int32_t N)
+{
+    if (N < 1 || N > mpcx_static_max_horizon()) return 0;
+    const size_t w = ((size_t)MPCX_STATIC_SCRATCH_BYTES - 512) / wave_bytes(N, MPCX_MAX_OBS);
+    return (int)(w < (size_t)kPlanWaves ? w : (size_t)kPlanWaves);
 }
 
 int mpcx_device_count(void)
@@ -551,7 +579,8 @@ int mpcx_ctx_solve(mpcx_ctx *c, const mpcx_batch *in, const mpcx_opts *opts, mpc
     return 0;
 }
 
-// The solve for callers that cannot allocate.  Its workspace is the file-scope device array below;
+// The solve for callers that cannot allocate.  Its workspace is the file-scope device array `scratch`
+// declared at the top of this file;
 // `scratch` names it on the host side only (a stand-in, not a device address): the address on each
 // device is looked up once, with that device current, and kept in g_scratch_ptr.
 int mpcx_solve_batch_static(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *out, void *stream)
@@ -574,10 +603,28 @@ int mpcx_solve_batch_static(const mpcx_batch *in, const mpcx_opts *opts, mpcx_re
     }
     const int nh = (opts->max_obs < 0) ? MPCX_MAX_OBS : opts->max_obs;
     const Plan plan = plan_for(in->B, in->N, (size_t)MPCX_STATIC_SCRATCH_BYTES - 512, opts->rti != 0);
+    hipStream_t q = static_cast<hipStream_t>(stream);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(q, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    StaticGuard &g = g_guard[dev];
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (!capturing) {
+        if (!g.done) HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));     // set-up, once per device
+        if (g.have && g.last != q && hipEventQuery(g.done) == hipErrorNotReady)
+            return fail(MPCX_E_BADARG, "overlapping mpcx_solve_batch_static calls on device %d: the previous call (another "
+                        "stream) has not finished and both would use the one built-in scratch", dev);
+        (void)hipGetLastError();
+    }
     // (the launch zeroes the problem counter in the scratch header itself; everything else a solve
     // reads of the workspace it has written before, so the last call's contents do not matter)
     HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(ptr), waves_to_launch(plan), plan.lanes,
-                            plan.coop_max, plan.lin_max, plan.coop_layout, kSlots, static_cast<hipStream_t>(stream)));
+                            plan.coop_max, plan.lin_max, plan.coop_layout, kSlots, q));
+    if (!capturing) {
+        HIP_TRY(hipEventRecord(g.done, q));
+        g.last = q;
+        g.have = true;
+    }
     return 0;
 }
 

@@ -3665,8 +3665,9 @@ __global__ void mpcx_header_kernel(int *counter, mpcx_opts *d_opts, mpcx_opts o)
     if (threadIdx.x == 0) *d_opts = o;
 }
 
-// initial guess without obstacles (reference core_solver.py:477-499): one thread per problem,
-// node by node; every store of a wavefront is one contiguous segment of xguess[i][c][:]
+// initial guess (reference core_solver.py:477-499, and :360-473 for problems with obstacles, up to
+// MPCX_MAX_OBS each: guess_adjust above): one thread per problem, node by node; every store of a
+// wavefront is one contiguous segment of xguess[i][c][:]
 __global__ void mpcx_guess_kernel(const double *pdata, const int32_t *n_obs, const double *width, int B, int N,
                                   double *xguess)
 {

@@ -14,11 +14,18 @@ Tick semantics, for vehicle b with horizon N and step h:
   3. shift:  xguess[k] = X[k+1] (k < N), xguess[N] = X[N];  xguess[0] = x+
              uguess[k] = U[k+1] (k < N-1), uguess[N-1] = U[N-1]
              pdata[X0] = x+
-A vehicle whose tick did not end with status 0 (QP failure, non-finite residual) keeps its
-PREVIOUS plan: in steps 2 and 3 its (X, U) are the tick's input guess instead of the failed
-iterate, so the plan it already had is carried on one more stage; ``failed`` holds the mask of
-such vehicles after ``advance`` and ``reset`` restarts chosen vehicles from the straight-line
-guess of core_solver.py:477-499 at their current state.
+A vehicle whose tick did not end with status 0 (QP failure, non-finite residual), or whose new
+iterate holds a non-finite number (the status of a real-time iteration reports the residuals from
+BEFORE its one step, so the iterate is checked here: ``plan_ok``), keeps its PREVIOUS plan: in steps
+2 and 3 its (X, U) are the tick's input guess instead of the failed iterate, so the plan it already
+had is carried on one more stage; ``failed`` holds the mask of such vehicles after ``advance`` and
+``reset`` restarts chosen vehicles from the straight-line guess of core_solver.py:477-499 at their
+current state.
+
+QP tolerances.  The library's defaults (1e-6 / 1e-8 / 1e-8 / 1e-6) are the ones that reproduce the
+reference's recorded trajectories; a tick then takes about 7 interior-point iterations per vehicle.
+A server that prefers shorter ticks to the last digits can pass ``qp_tol="loose"`` (all four at the
+NLP tolerance 1e-3, about 4.5 iterations per tick): see ``QP_TOL_PRESETS``.
 The goal, bounds and corridor stay as packed.  PyTorch is used for device
 memory and for the elementwise shift / plant step only; the solve is the HIP
 library's.  There is no CPU fallback.
@@ -35,6 +42,20 @@ from . import _lib
 from .batch import F_X0, F_L, F_H
 
 
+# (stationarity, equalities, inequalities, complementarity) of the QP solver, by name
+QP_TOL_PRESETS = {
+    "reference": (1e-6, 1e-8, 1e-8, 1e-6),      # the library's defaults
+    "loose": (1e-3, 1e-3, 1e-3, 1e-3),          # QP stopped at the NLP tolerance of core_solver.py:252
+}
+
+
+def plan_ok(xp, status, X, U):
+    """[B] mask of vehicles whose tick produced a usable plan: status 0 and every number of the new
+    iterate finite.  xp = numpy or torch module."""
+    finite = xp.isfinite(X).reshape(X.shape[0], -1).all(1) & xp.isfinite(U).reshape(U.shape[0], -1).all(1)
+    return (status == 0) & finite
+
+
 def plant_step(xp, x, u, h, wheelbase):
     """One RK4 step of the kinematic bicycle; x [B,5], u [B,2]; xp = numpy or torch module."""
     def f(s):
@@ -48,9 +69,10 @@ def plant_step(xp, x, u, h, wheelbase):
 
 
 class RtiServer:
-    def __init__(self, packed, X=None, U=None, opts=None, device=0):
+    def __init__(self, packed, X=None, U=None, opts=None, device=0, qp_tol=None):
         """packed: PackedBatch (problem table + initial guess).  X [B,N+1,5], U [B,N,2]:
-        a previous solution to start from (else the packed guess and zero inputs)."""
+        a previous solution to start from (else the packed guess and zero inputs).
+        qp_tol: None = as in ``opts``; a key of QP_TOL_PRESETS or four numbers."""
         self.torch = torch
         self.lib = _lib.load_library()
         if self.lib.mpcx_device_count() <= 0:
@@ -63,6 +85,9 @@ class RtiServer:
         self.opts = _lib.MpcxOpts.from_buffer_copy(opts) if opts is not None else _lib.default_opts(self.lib)
         self.opts.rti = 1
         self.opts.max_obs = int(packed.n_obs.max()) if B else 0
+        if qp_tol is not None:
+            tol = QP_TOL_PRESETS[qp_tol] if isinstance(qp_tol, str) else tuple(float(v) for v in qp_tol)
+            (self.opts.qp_tol_stat, self.opts.qp_tol_eq, self.opts.qp_tol_ineq, self.opts.qp_tol_comp) = tol
         self.failed = torch.zeros(B, dtype=torch.bool, device=self.dev)
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
         self.pdata = to(packed.pdata)
@@ -86,6 +111,24 @@ class RtiServer:
                                    self.sqp_iter.data_ptr(), self.qp_iter.data_ptr(),
                                    self.cost.data_ptr(), self.res.data_ptr())
         self.ticks = 0
+        self._warm()
+
+    def _warm(self):
+        """Everything a tick does for the first time, done once here on copies: the first use of each
+        elementwise kernel loads its code and the first temporaries come from the driver, not from
+        torch's cache -- hundreds of milliseconds that would otherwise land in the first tick."""
+        if self.B == 0:
+            return
+        t = self.torch
+        self.status.zero_()
+        self.X.copy_(self.xguess.permute(2, 0, 1))
+        self.U.copy_(self.uguess.permute(2, 0, 1))
+        saved = (self.xguess.clone(), self.uguess.clone(), self.pdata[F_X0:F_X0 + 5].clone(), self.ticks)
+        self.advance()
+        self.xguess.copy_(saved[0]); self.uguess.copy_(saved[1]); self.pdata[F_X0:F_X0 + 5] = saved[2]
+        self.ticks = saved[3]
+        self.failed.zero_()
+        t.cuda.synchronize(self.dev)
 
     def host_inputs(self):
         """The inputs of the NEXT tick as a PackedBatch on the host (for checking)."""
@@ -104,7 +147,7 @@ class RtiServer:
     def advance(self):
         """Steps 2 and 3 of a tick on the device; returns the applied inputs [B,2]."""
         t = self.torch
-        ok = (self.status == 0)[:, None, None]
+        ok = plan_ok(t, self.status, self.X, self.U)[:, None, None]
         self.failed = ~ok[:, 0, 0]
         # failed vehicles carry their previous plan (this tick's input guess) on
         X = t.where(ok, self.X, self.xguess.permute(2, 0, 1))
@@ -124,8 +167,9 @@ class RtiServer:
 
     def reset(self, vehicles=None):
         """Restart vehicles (index tensor / array, default: the failed ones) from the straight-line
-        guess at their current state and zero inputs.  Obstacle-free fleets only: the guess is the
-        library's device routine (the obstacle branch of the reference's guess runs on the host)."""
+        guess at their current state and zero inputs.  The guess is the library's device routine
+        (mpcx_initial_guess_device): the reference's loop bit for bit without obstacles, and with up to
+        MPCX_MAX_OBS obstacles its rules with last-bit differences in pow and arctan2 (include/mpcx.h)."""
         t = self.torch
         if vehicles is None:
             vehicles = t.nonzero(self.failed)[:, 0]

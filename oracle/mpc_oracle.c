@@ -1221,6 +1221,61 @@ int mpcx_oracle_solve_batch(const mpcx_batch *in, const mpcx_opts *o, mpcx_resul
     return fail ? MPCX_E_NOMEM : 0;
 }
 
+/* Debug entry: the constraint set of problem b's FIRST QP (linearisation at the initial guess), for
+ * feasibility studies with an independent LP solver.  Doubles per stage k = 0..N, MPCX_ORACLE_QP_STRIDE each:
+ *   [0,25)  A row-major   [25,35) B row-major   [35,40) gap b   (interval k -> k+1; zeros at k = N)
+ *   [40,45) x0 - x_0 at k = 0 (the fixed value of the state part of the QP variable), zeros elsewhere
+ *   then for every row r = 0..MAXR-1 six doubles: present (1/0), c, jx, jy, lo, up
+ * so that the QP's feasible set is  dx_(k+1) = A dx_k + B du_k + b,  dx_0 = x0 - x_0,
+ * lo - c <= J_r [du; dx] <= up - c  for the rows present (J_r = e_r for r < 7, (jx, jy) on (x, y) else). */
+#define MPCX_ORACLE_QP_STRIDE (45 + 6 * MAXR)
+int mpcx_oracle_qp_stride(void) { return MPCX_ORACLE_QP_STRIDE; }
+
+int mpcx_oracle_first_qp(const mpcx_batch *in, const mpcx_opts *o, int b, double *out)
+{
+    if (!in || !o || !out || in->N < 1 || b < 0 || b >= in->B || !in->xguess) return MPCX_E_BADARG;
+    g_stage0_rows = getenv("MPCX_ORACLE_STAGE0_ROWS") ? atoi(getenv("MPCX_ORACLE_STAGE0_ROWS")) : 0;
+    const int N = in->N, B = in->B;
+    stage *st = (stage *)calloc((size_t)N + 1, sizeof(stage));
+    if (!st) return MPCX_E_NOMEM;
+    problem pb;
+    load_problem(in, b, &pb);
+    if (pb.nobs < 0 || pb.nobs > MPCX_MAX_OBS) { free(st); return MPCX_E_BADARG; }
+    for (int k = 0; k <= N; ++k) {
+        for (int i = 0; i < NX; ++i) st[k].x[i] = (real)in->xguess[((size_t)k * NX + i) * B + b];
+        for (int c = 0; c < NU; ++c)
+            st[k].u[c] = (k < N && in->uguess) ? (real)in->uguess[((size_t)k * NU + c) * B + b] : (real)0.0;
+    }
+    linearize(&pb, o, st);
+    for (int k = 0; k <= N; ++k) {
+        const stage *s = &st[k];
+        double *q = out + (size_t)k * MPCX_ORACLE_QP_STRIDE;
+        for (int i = 0; i < MPCX_ORACLE_QP_STRIDE; ++i) q[i] = 0.0;
+        if (k < N) {
+            for (int i = 0; i < NX; ++i) {
+                for (int j = 0; j < NX; ++j) q[i * NX + j] = R2D(s->A[i][j]);
+                for (int c = 0; c < NU; ++c) q[25 + i * NU + c] = R2D(s->B[i][c]);
+                q[35 + i] = R2D(s->b[i]);
+            }
+        }
+        if (k == 0)
+            for (int i = 0; i < NX; ++i) q[40 + i] = R2D(pb.x0[i] - s->x[i]);
+        const real *lo = row_lo(&pb, k), *up = row_up(&pb, k);
+        for (int r = s->r0; r < s->r1; ++r) {
+            if (!((s->rmask >> r) & 1u)) continue;
+            double *w = q + 45 + 6 * r;
+            w[0] = 1.0;
+            w[1] = R2D(s->c[r]);
+            w[2] = (r >= ROW_G0) ? R2D(s->jx[r]) : 0.0;
+            w[3] = (r >= ROW_G0) ? R2D(s->jy[r]) : 0.0;
+            w[4] = R2D(lo[r]);
+            w[5] = R2D(up[r]);
+        }
+    }
+    free(st);
+    return 0;
+}
+
 /* sin/cos as the solver computes them, for the accuracy test */
 void mpcx_oracle_sincos(double x, double *s, double *c)
 {

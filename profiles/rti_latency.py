@@ -1,6 +1,6 @@
 """Tick latency of the receding-horizon RTI server on one GPU, or on several with one process each.
 
-Usage on the GPU box:  python profiles/rti_latency.py [vehicles] [ticks]
+Usage on the GPU box:  python profiles/rti_latency.py [vehicles] [ticks] [qp_tol preset: reference | loose]
   or, one rank per GPU:  python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 \
                              --master-port P profiles/rti_latency.py [vehicles] [ticks]
 Every rank serves a contiguous slice of the fleet (mpc_amd.parallel.shard_range) with no exchange
@@ -8,7 +8,9 @@ between ranks; the latency of a tick of the fleet is the slowest rank's, so the 
 reduced with MAX over the ranks (gloo, a vector of `ticks` doubles, after the run).
 Fleet: the first `vehicles` problems of the synthetic benchmark distribution that a full
 solve converges on, started from that solution.  A tick = one linearisation + one QP per
-vehicle, the plant step and the shift, timed with HIP events on the launch stream.
+vehicle, the plant step and the shift, timed with HIP events on the launch stream (one pair around
+the solve, one around shift + plant step), and the host's own clock around the enqueue of each tick;
+the five slowest ticks are listed with that split.
 """
 import json
 import os
@@ -28,6 +30,7 @@ from mpc_amd.parallel import shard_range  # noqa: E402
 
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 TICKS = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+QP_TOL = sys.argv[3] if len(sys.argv) > 3 else None
 RANK, WORLD = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 DEVICE = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
 torch.cuda.set_device(DEVICE)
@@ -45,21 +48,30 @@ ok = ok[lo:hi]
 V_ALL, V = V, hi - lo
 pick = lambda a, ax: np.ascontiguousarray(np.take(a, ok, axis=ax))
 fleet = type(pool)(V, pool.N, pick(pool.pdata, 1), pick(pool.n_obs, 0), pick(pool.xguess, 2), pool.duration)
-srv = RtiServer(fleet, X=full["X"][ok], U=full["U"][ok], device=DEVICE)
+srv = RtiServer(fleet, X=full["X"][ok], U=full["U"][ok], device=DEVICE, qp_tol=QP_TOL)
 print(f"rank {RANK}: fleet of {V} vehicles ready ({time.time() - t0:.1f} s for the initial full solve of {pool.B})", flush=True)
 stream = torch.cuda.current_stream()
-ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(TICKS)]
+ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(TICKS)]
 qp = []
-for i, (e0, e1) in enumerate(ev):
+host_ms = np.zeros(TICKS)
+for i, (e0, em, e1) in enumerate(ev):
+    h0 = time.perf_counter()
     e0.record(stream)
-    srv.tick()
+    srv.solve()
+    em.record(stream)
+    srv.advance()
     e1.record(stream)
+    host_ms[i] = 1e3 * (time.perf_counter() - h0)
     if i % 100 == 99:
         torch.cuda.synchronize()
         qp.append(float(srv.qp_iter.double().mean()))
         print(f"rank {RANK} tick {i + 1}: mean IP iterations {qp[-1]:.1f}, status!=0: {int((srv.status != 0).sum())}", flush=True)
 torch.cuda.synchronize()
-ms = np.array([e0.elapsed_time(e1) for e0, e1 in ev])
+ms = np.array([e0.elapsed_time(e1) for e0, _, e1 in ev])
+solve_ms = np.array([e0.elapsed_time(em) for e0, em, _ in ev])
+slow = np.argsort(-ms)[:5]
+slowest = [{"tick": int(i), "ms": float(ms[i]), "solve_ms": float(solve_ms[i]), "shift_plant_ms": float(ms[i] - solve_ms[i]),
+            "host_enqueue_ms": float(host_ms[i])} for i in slow]
 if WORLD > 1:
     t = torch.from_numpy(ms.copy())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -76,5 +88,8 @@ else:
 if RANK == 0:
   print(json.dumps({"vehicles": V_ALL, "gpus": WORLD, "ticks": TICKS, "N": fleet.N,
                   "tick_ms_p50": float(np.percentile(ms, 50)), "tick_ms_p99": float(np.percentile(ms, 99)),
-                  "tick_ms_max": float(ms.max()), "vehicle_ticks_per_s": V_ALL / (np.median(ms) * 1e-3),
+                  "tick_ms_max": float(ms.max()), "tick_ms_max_after_first": float(ms[1:].max()) if TICKS > 1 else None,
+                  "solve_ms_p50": float(np.percentile(solve_ms, 50)), "host_enqueue_ms_p50": float(np.percentile(host_ms, 50)),
+                  "qp_tol": QP_TOL or "reference", "mean_ip_iterations": qp[-1] if qp else None,
+                  "slowest_ticks_rank0": slowest, "vehicle_ticks_per_s": V_ALL / (np.median(ms) * 1e-3),
                   "mean_distance_to_goal_m": mean_d}))

@@ -32,6 +32,11 @@ def load(path=ORACLE_SO):
     lib.mpcx_oracle_sincos.restype = None
     lib.mpcx_oracle_rk4.argtypes = [C.c_double, C.c_double] + [C.POINTER(C.c_double)] * 5
     lib.mpcx_oracle_rk4.restype = None
+    lib.mpcx_oracle_qp_stride.argtypes = []
+    lib.mpcx_oracle_qp_stride.restype = C.c_int
+    lib.mpcx_oracle_first_qp.argtypes = [C.POINTER(_lib.MpcxBatch), C.POINTER(_lib.MpcxOpts), C.c_int,
+                                         C.POINTER(C.c_double)]
+    lib.mpcx_oracle_first_qp.restype = C.c_int
     _cache[path] = lib
     return lib
 
@@ -60,3 +65,19 @@ def solve_packed(packed, opts=None, device=0, nthreads=None, lib=None):
     if rc != 0:
         raise RuntimeError(f"oracle failed: {rc}")
     return out
+
+
+def first_qp(packed, b, opts=None):
+    """Constraint set of problem b's first QP (linearisation at the initial guess) as the oracle poses it:
+    array [N+1, stride], layout in oracle/mpc_oracle.c (mpcx_oracle_first_qp)."""
+    lib = load()
+    opts = opts or default_opts()
+    if packed.xguess is None:
+        import dataclasses
+        packed = dataclasses.replace(packed, xguess=packed.guess())
+    bs = _lib.batch_struct(packed)
+    q = np.zeros((packed.N + 1, lib.mpcx_oracle_qp_stride()))
+    rc = lib.mpcx_oracle_first_qp(C.byref(bs), C.byref(opts), int(b), q.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc != 0:
+        raise RuntimeError(f"mpcx_oracle_first_qp failed: {rc}")
+    return q

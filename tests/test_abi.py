@@ -27,7 +27,7 @@ def test_exports_match_header():
             "mpcx_max_horizon"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mpcx.h but not exported"
-    assert lib.mpcx_version() == 106
+    assert lib.mpcx_version() == 107
 
 
 def test_struct_layout_and_defaults():
@@ -65,6 +65,10 @@ def test_bad_arguments_and_no_device():
     assert lib.mpcx_solve_batch(C.byref(b), C.byref(o), C.byref(r), 0) == -1
     assert b"too large" in lib.mpcx_last_error()
     b.N = p.N
+    # limits of the entry point that allocates nothing, computed by the library from its record layout
+    ns = lib.mpcx_static_max_horizon()
+    assert 500 < ns < 2000 and lib.mpcx_static_max_wavefronts(ns) >= 1 and lib.mpcx_static_max_wavefronts(ns + 1) == 0
+    assert 8 <= lib.mpcx_static_max_wavefronts(50) <= 64 and lib.mpcx_static_max_wavefronts(0) == 0
     h = C.c_void_p()
     assert lib.mpcx_ctx_create(None, 0) == -1
     lib.mpcx_ctx_destroy(None)

@@ -211,6 +211,11 @@ def test_find_paths_isolates_bad_problems(oracle, capsys):
     capsys.readouterr()
     find_paths([same], s, solver=oracle.solve_packed)
     assert "Points A and B cannot be the same" in capsys.readouterr().out
+    # ... and a problem dropped for the obstacle limit (which the reference does not have) says so
+    many.verbose = True
+    find_paths([many], s, solver=oracle.solve_packed)
+    said = capsys.readouterr().out
+    assert "at most 4 obstacles" in said and "the reference has none" in said
     # generate_controls_batch without an error dict still raises, like one reference call would
     from mpc_amd.core_solver import generate_controls_batch
     with pytest.raises(ValueError):
@@ -340,3 +345,22 @@ def test_result_files_load_like_the_reference(oracle, tmp_path):
     assert combined["t"].shape == (1191,) and combined["status"] == 0
     assert [s["name"] for s in combined["segments"]] == [s["name"] for s in sc.sequential_segments]
     assert combined["segments"][0]["ego"].corridor_width == sc.sequential_segments[0].get("corridor_width", 2.0)
+
+
+def test_rti_plan_ok_rejects_non_finite_iterates():
+    """A real-time iteration reports status 0 with the residuals from before its one step; the server
+    therefore checks the new iterate itself and keeps a vehicle's previous plan when any number of it
+    is not finite (poisoned guess, overflowing step)."""
+    import torch
+    from mpc_amd.rti import plan_ok, QP_TOL_PRESETS
+    B, N = 6, 4
+    X = np.zeros((B, N + 1, 5)); U = np.zeros((B, N, 2))
+    status = np.array([0, 0, 4, 0, 0, 1], dtype=np.int32)
+    X[1, 2, 3] = np.nan
+    U[3, 0, 1] = np.inf
+    X[4, N, 0] = -np.inf
+    want = np.array([True, False, False, False, False, False])
+    assert np.array_equal(plan_ok(np, status, X, U), want)
+    got = plan_ok(torch, torch.from_numpy(status), torch.from_numpy(X), torch.from_numpy(U))
+    assert np.array_equal(got.numpy(), want)
+    assert QP_TOL_PRESETS["reference"] == (1e-6, 1e-8, 1e-8, 1e-6) and set(QP_TOL_PRESETS["loose"]) == {1e-3}

@@ -164,3 +164,64 @@ def test_multiplier_step_forms_agree(oracle, monkeypatch):
     assert np.abs(other["X"][ok] - plain["X"][ok]).max() < 1e-7
     assert np.abs(other["U"][ok] - plain["U"][ok]).max() < 1e-7
     assert not np.array_equal(other["X"], plain["X"])      # the switch does change the rounding
+
+
+def _first_qp_is_feasible(q, N):
+    """Is the constraint set of a QP (oracle_lib.first_qp layout) non-empty?  Decided by an LP solver that
+    shares nothing with the interior point under test (scipy's HiGHS, zero objective)."""
+    import scipy.sparse as sp
+    from scipy.optimize import linprog
+    maxr = (q.shape[1] - 45) // 6
+    nv = 7 * (N + 1)                                    # [du_k (2); dx_k (5)] per stage
+    lb, ub = np.full(nv, -np.inf), np.full(nv, np.inf)
+    er, ec, ev, beq = [], [], [], []
+    for i in range(5):                                  # dx_0 = x0 - x_0
+        er.append(len(beq)); ec.append(2 + i); ev.append(1.0); beq.append(q[0, 40 + i])
+    for k in range(N):                                  # dx_(k+1) - A dx_k - B du_k = b
+        A, Bm, gap = q[k, 0:25].reshape(5, 5), q[k, 25:35].reshape(5, 2), q[k, 35:40]
+        for i in range(5):
+            e = len(beq)
+            er.append(e); ec.append(7 * (k + 1) + 2 + i); ev.append(1.0)
+            for j in range(5):
+                er.append(e); ec.append(7 * k + 2 + j); ev.append(-A[i, j])
+            for c in range(2):
+                er.append(e); ec.append(7 * k + c); ev.append(-Bm[i, c])
+            beq.append(gap[i])
+    lb[7 * N:7 * N + 2] = ub[7 * N:7 * N + 2] = 0.0     # the last stage has no input
+    ur, uc, uv, bub = [], [], [], []
+    for k in range(N + 1):
+        for r in range(maxr):
+            present, c, jx, jy, lo, up = q[k, 45 + 6 * r:51 + 6 * r]
+            if present == 0.0:
+                continue
+            if r < 7:                                   # box rows are bounds of one variable
+                lb[7 * k + r] = max(lb[7 * k + r], lo - c)
+                ub[7 * k + r] = min(ub[7 * k + r], up - c)
+            else:                                       # corridor / obstacle rows act on (x, y)
+                for sgn, rhs in ((1.0, up - c), (-1.0, -(lo - c))):
+                    i = len(bub)
+                    ur += [i, i]; uc += [7 * k + 2, 7 * k + 3]; uv += [sgn * jx, sgn * jy]; bub.append(rhs)
+    if np.any(lb > ub):
+        return False
+    res = linprog(np.zeros(nv), A_ub=sp.csr_matrix((uv, (ur, uc)), shape=(len(bub), nv)), b_ub=np.array(bub),
+                  A_eq=sp.csr_matrix((ev, (er, ec)), shape=(len(beq), nv)), b_eq=np.array(beq),
+                  bounds=np.stack([lb, ub], 1), method="highs")
+    assert res.status in (0, 2), res.message
+    return res.status == 0
+
+
+def test_benchmark_failures_are_infeasible_qps(oracle):
+    """Nine in ten problems of the headline benchmark distribution end with status 4 after ONE QP.  That is
+    the problem, not the interior point: for each of the first 400 problems of the distribution the
+    constraint set of the first linearised QP (dynamics rows, fixed initial state, boxes, corridor,
+    terminal box) is handed to an independent LP solver, and it is empty exactly where the oracle reports
+    `QP failure after one QP`; where it is non-empty the oracle goes on (and, on this sample, converges)."""
+    from mpc_amd.synthetic import synthetic_batch
+    n = 400
+    packed = synthetic_batch(n)
+    ref = oracle.solve_packed(packed)
+    failed_first = (ref["status"] == 4) & (ref["sqp_iter"] == 1)
+    feasible = np.array([_first_qp_is_feasible(oracle.first_qp(packed, b), packed.N) for b in range(n)])
+    assert np.array_equal(~feasible, failed_first)
+    assert 0.85 < failed_first.mean() < 0.95                    # the benchmark's status mix
+    assert np.all(ref["status"][feasible] == 0)
