@@ -18,6 +18,12 @@ RCCL sees, and a mismatch with --gpus is an error, not a silent single-GPU run.
                     where its longest problem sits, sets the time: per-rank times are in the line).
   --scaling strong  ONE batch of --batch problems, contiguous slices per rank, results gathered to
                     rank 0 over RCCL (device tensors) inside the timed region.
+
+Besides the headline the same line carries, by default:
+  N = 1:  "reachable": a few steps of the workload whose goals are reachable by construction (about
+          95 % converge; on the headline distribution 91.5 % of the first QPs are infeasible);
+  N > 1 (weak): "strong": the SAME run repeated as ONE batch of --batch problems cut into contiguous
+          slices, one per rank, with the RCCL gather to rank 0 inside the timed region.
 """
 import argparse
 import ctypes as C
@@ -59,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--lib", default=None, help="another build of the library (diagnostic builds)")
     ap.add_argument("--cpu-sample", type=int, default=262144, help="problems timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-to-host timing of the batch")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="headline only: neither the reachable-workload block (N = 1) nor the strong-scaling block (N > 1)")
+    ap.add_argument("--extra-steps", type=int, default=3, help="timed steps of those blocks (one warm-up step each)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="control-flow rehearsal of the multi-rank paths where only one GPU is there: every rank "
                          "uses GPU 0 and the collectives run over gloo on host copies (RCCL refuses two ranks on "
@@ -174,125 +183,185 @@ def main():
 
     seed0 = SEED if args.seed is None else args.seed
     strong = args.scaling == "strong"
-    if strong:
-        whole = make_batch(args, seed0, args.batch)
-        if args.order:
-            whole = reorder(args, whole)
-        lo, hi = shard_range(whole.B, rank, world)
-        packed = whole.slice(lo, hi)
-        B_total = whole.B
-    else:
+    stream = torch.cuda.current_stream()
+
+    def prepare(is_strong, reachable=False):
+        """This rank's problems of a workload: (packed, B_total)."""
+        if reachable:
+            from mpc_amd.synthetic import reachable_batch
+            return reachable_batch(args.batch, seed=seed0, device_guess=False if args.host_guess else "all"), args.batch * world
+        if is_strong:
+            whole = make_batch(args, seed0, args.batch)
+            if args.order:
+                whole = reorder(args, whole)
+            lo, hi = shard_range(whole.B, rank, world)
+            return whole.slice(lo, hi), whole.B
         packed = make_batch(args, seed0 + (rank if args.distinct_batches else 0), args.batch)
         if args.order:
             packed = reorder(args, packed)
-        B_total = packed.B * world
-    B, N = packed.B, packed.N
-
-    # inputs resident in HBM before the timed region
-    d_pd = torch.from_numpy(packed.pdata).to(dev)
-    d_no = torch.from_numpy(packed.n_obs).to(dev)
-    d_xg = torch.from_numpy(packed.xguess).to(dev) if packed.xguess is not None else None
-    out = {"X": torch.empty((B, N + 1, 5), dtype=torch.float64, device=dev),
-           "U": torch.empty((B, N, 2), dtype=torch.float64, device=dev),
-           "status": torch.empty(B, dtype=torch.int32, device=dev),
-           "sqp_iter": torch.empty(B, dtype=torch.int32, device=dev),
-           "qp_iter": torch.empty(B, dtype=torch.int32, device=dev),
-           "cost": torch.empty(B, dtype=torch.float64, device=dev),
-           "res": torch.empty((4, B), dtype=torch.float64, device=dev)}
-    ws_bytes = lib.mpcx_workspace_bytes(max(B, 1), N)
-    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    assert d_ws.data_ptr() % 256 == 0
-
-    bs = _lib.MpcxBatch(B, N, d_pd.data_ptr(), d_no.data_ptr(), d_xg.data_ptr() if d_xg is not None else None, None)
-    rs = _lib.MpcxResult(*(out[k].data_ptr() for k in ("X", "U", "status", "sqp_iter", "qp_iter", "cost", "res")))
-    stream = torch.cuda.current_stream()
-    gathered = None
-    gather_ev = []
-
-    def step(timed=False):
-        nonlocal gathered
-        if B > 0:
-            rc = lib.mpcx_solve_batch_device(C.byref(bs), C.byref(opts), C.byref(rs),
-                                             d_ws.data_ptr(), ws_bytes, stream.cuda_stream)
-            if rc != 0:
-                raise RuntimeError(lib.mpcx_last_error().decode())
-        if strong and world > 1:
-            # the one exchange of the path: every rank's slice of the results to rank 0, over RCCL
-            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            g0.record(stream)
-            gathered = gather_to_root({k: coll(v) for k, v in out.items()} if rehearsal else out, B_total, dst=0)
-            g1.record(stream)
-            if timed:
-                gather_ev.append((g0, g1))
+        return packed, packed.B * world
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in ev:
-        e0.record(stream)       # the solve is queued on this same stream (passed to the library)
-        step(timed=True)
-        e1.record(stream)
-    torch.cuda.synchronize()
-    own_elapsed = time.perf_counter() - t0
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    step_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
-    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_ev])) if gather_ev else 0.0
-    kernel_ms = (float(np.mean(step_ms)) - gather_ms) if ev else 0.0
+    def measure(packed, B_total, is_strong, n_steps, n_warmup):
+        """n_warmup untimed and n_steps timed solves of this rank's problems (plus, strong scaling, the
+        gather of every rank's results to rank 0), bracketed by barrier + synchronize; the counters
+        reduced over the ranks.  Returns everything the report needs."""
+        B, N = packed.B, packed.N
+        # inputs resident in HBM before the timed region
+        d_pd = torch.from_numpy(packed.pdata).to(dev)
+        d_no = torch.from_numpy(packed.n_obs).to(dev)
+        d_xg = torch.from_numpy(packed.xguess).to(dev) if packed.xguess is not None else None
+        out = {"X": torch.empty((B, N + 1, 5), dtype=torch.float64, device=dev),
+               "U": torch.empty((B, N, 2), dtype=torch.float64, device=dev),
+               "status": torch.empty(B, dtype=torch.int32, device=dev),
+               "sqp_iter": torch.empty(B, dtype=torch.int32, device=dev),
+               "qp_iter": torch.empty(B, dtype=torch.int32, device=dev),
+               "cost": torch.empty(B, dtype=torch.float64, device=dev),
+               "res": torch.empty((4, B), dtype=torch.float64, device=dev)}
+        ws_bytes = lib.mpcx_workspace_bytes(max(B, 1), N)
+        d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        assert d_ws.data_ptr() % 256 == 0
+        bs = _lib.MpcxBatch(B, N, d_pd.data_ptr(), d_no.data_ptr(), d_xg.data_ptr() if d_xg is not None else None, None)
+        rs = _lib.MpcxResult(*(out[k].data_ptr() for k in ("X", "U", "status", "sqp_iter", "qp_iter", "cost", "res")))
+        gathered = [None]
+        gather_ev = []
 
-    # outcome counters reduced on the device
-    d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
-    if B > 0 and lib.mpcx_batch_stats_device(out["status"].data_ptr(), out["sqp_iter"].data_ptr(), out["qp_iter"].data_ptr(),
-                                             B, d_stats.data_ptr(), C.c_void_p(stream.cuda_stream)) != 0:
-        raise RuntimeError(lib.mpcx_last_error().decode())
-    stats = d_stats.cpu().numpy()
-    n_conv = int(stats[0])
-    status = out["status"].cpu().numpy()
-    sqp_it = out["sqp_iter"].cpu().numpy()
-    qp_it = out["qp_iter"].cpu().numpy()
-    assert n_conv == int((status == 0).sum())
+        def step(timed=False):
+            if B > 0:
+                rc = lib.mpcx_solve_batch_device(C.byref(bs), C.byref(opts), C.byref(rs),
+                                                 d_ws.data_ptr(), ws_bytes, stream.cuda_stream)
+                if rc != 0:
+                    raise RuntimeError(lib.mpcx_last_error().decode())
+            if is_strong and world > 1:
+                # the one exchange of the path: every rank's slice of the results to rank 0, over RCCL
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record(stream)
+                gathered[0] = gather_to_root({k: coll(v) for k, v in out.items()} if rehearsal else out, B_total, dst=0)
+                g1.record(stream)
+                if timed:
+                    gather_ev.append((g0, g1))
+
+        for _ in range(n_warmup):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)]
+        t0 = time.perf_counter()
+        for e0, e1 in ev:
+            e0.record(stream)       # the solve is queued on this same stream (passed to the library)
+            step(timed=True)
+            e1.record(stream)
+        torch.cuda.synchronize()
+        own_elapsed = time.perf_counter() - t0
+        barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        step_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
+        gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_ev])) if gather_ev else 0.0
+        kernel_ms = (float(np.mean(step_ms)) - gather_ms) if ev else 0.0
+
+        # outcome counters reduced on the device
+        d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
+        if B > 0 and lib.mpcx_batch_stats_device(out["status"].data_ptr(), out["sqp_iter"].data_ptr(), out["qp_iter"].data_ptr(),
+                                                 B, d_stats.data_ptr(), C.c_void_p(stream.cuda_stream)) != 0:
+            raise RuntimeError(lib.mpcx_last_error().decode())
+        stats = d_stats.cpu().numpy()
+        n_conv = int(stats[0])
+        status = out["status"].cpu().numpy()
+        sqp_it = out["sqp_iter"].cpu().numpy()
+        qp_it = out["qp_iter"].cpu().numpy()
+        assert n_conv == int((status == 0).sum())
+        fl_dense = flops.flops_from_stats(stats, N)
+        fl = flops.flops_from_stats(stats, N, sparse=True)
+        assert fl_dense == flops.algorithmic_flops(status, sqp_it, qp_it, N)
+        conv = status == 0
+        fl_conv = flops.algorithmic_flops(status[conv], sqp_it[conv], qp_it[conv], N, sparse=True)
+
+        tot = torch.tensor([elapsed, float(n_conv), fl, fl_dense, float(B), float(stats[6])], dtype=torch.float64, device=dev)
+        per_rank = torch.tensor([own_elapsed * 1e3 / max(n_steps, 1), kernel_ms, float(qp_it.max()) if B else 0.0, float(B)],
+                                dtype=torch.float64, device=dev)
+        if world > 1:
+            mx = coll(tot[:1].clone())
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            sm = coll(tot[1:].clone())
+            dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            elapsed = float(mx[0])
+            n_conv_all, fl_all, fl_dense_all, B_all, qp_all = (float(v) for v in sm)
+            per_rank = coll(per_rank)
+            pr = [torch.empty_like(per_rank) for _ in range(world)]
+            dist.all_gather(pr, per_rank)
+            per_rank_rows = [[float(v) for v in t] for t in pr]
+        else:
+            n_conv_all, fl_all, fl_dense_all, B_all, qp_all = float(n_conv), fl, fl_dense, float(B), float(stats[6])
+            per_rank_rows = [[float(v) for v in per_rank]]
+
+        if is_strong and world > 1 and rank == 0:
+            # the gathered arrays are the whole batch in the caller's order
+            g = gathered[0]
+            assert g["status"].shape[0] == B_total
+            assert int((g["status"] == 0).sum()) == int(n_conv_all)
+            assert torch.equal(g["X"][:B], coll(out["X"]))
+        return dict(B=B, N=N, B_total=B_total, packed=packed, out=out, elapsed=elapsed, kernel_ms=kernel_ms, gather_ms=gather_ms,
+                    stats=stats, status=status, sqp_it=sqp_it, qp_it=qp_it, n_conv=n_conv, fl=fl, fl_dense=fl_dense,
+                    fl_conv=fl_conv, n_conv_all=n_conv_all, fl_all=fl_all, fl_dense_all=fl_dense_all, B_all=B_all,
+                    qp_all=qp_all, per_rank_rows=per_rank_rows, steps=max(n_steps, 1))
+
+    def per_rank_list(R):
+        return [{"rank": i, "ms_per_step": r[0], "kernel_ms": r[1], "longest_problem_ip_iterations": int(r[2]),
+                 "problems": int(r[3])} for i, r in enumerate(R["per_rank_rows"])]
+
+    packed, B_total = prepare(strong)
+    R = measure(packed, B_total, strong, args.steps, args.warmup)
+    B, N = R["B"], R["N"]
+    out, status, sqp_it, qp_it, stats = R["out"], R["status"], R["sqp_it"], R["qp_it"], R["stats"]
+    elapsed, kernel_ms, gather_ms = R["elapsed"], R["kernel_ms"], R["gather_ms"]
+    n_conv, fl, fl_dense, fl_conv = R["n_conv"], R["fl"], R["fl_dense"], R["fl_conv"]
+    n_conv_all, B_all, qp_all = R["n_conv_all"], R["B_all"], R["qp_all"]
     if os.environ.get("MPCX_BENCH_SAVE_COUNTS"):
         np.save(os.environ["MPCX_BENCH_SAVE_COUNTS"], qp_it)
-    fl_dense = flops.flops_from_stats(stats, N)
-    fl = flops.flops_from_stats(stats, N, sparse=True)
-    assert fl_dense == flops.algorithmic_flops(status, sqp_it, qp_it, N)
 
-    conv = status == 0
-    fl_conv = flops.algorithmic_flops(status[conv], sqp_it[conv], qp_it[conv], N, sparse=True)
-
-    tot = torch.tensor([elapsed, float(n_conv), fl, fl_dense, float(B), float(stats[6])], dtype=torch.float64, device=dev)
-    per_rank = torch.tensor([own_elapsed * 1e3 / max(args.steps, 1), kernel_ms, float(qp_it.max()) if B else 0.0],
-                            dtype=torch.float64, device=dev)
-    if world > 1:
-        mx = coll(tot[:1].clone())
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = coll(tot[1:].clone())
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0])
-        n_conv_all, fl_all, fl_dense_all, B_all, qp_all = (float(v) for v in sm)
-        per_rank = coll(per_rank)
-        pr = [torch.empty_like(per_rank) for _ in range(world)]
-        dist.all_gather(pr, per_rank)
-        per_rank_rows = [[float(v) for v in t] for t in pr]
-    else:
-        n_conv_all, fl_all, fl_dense_all, B_all, qp_all = float(n_conv), fl, fl_dense, float(B), float(stats[6])
-        per_rank_rows = [[float(v) for v in per_rank]]
-
-    if strong and world > 1 and rank == 0:
-        # the gathered arrays are the whole batch in the caller's order
-        assert gathered["status"].shape[0] == B_total
-        assert int((gathered["status"] == 0).sum()) == int(n_conv_all)
-        assert torch.equal(gathered["X"][:B], coll(out["X"]))
+    # the second block of the line (every rank takes part; rank 0 reports)
+    headline_workload = not (args.obstacle or args.reachable or args.order or args.host_guess)
+    extra = None
+    if not args.no_extra and headline_workload and not strong and B > 0:
+        if world > 1:
+            # the north-star's configuration: ONE batch cut into contiguous slices, results gathered over RCCL
+            p2, bt2 = prepare(True)
+            S = measure(p2, bt2, True, args.extra_steps, 1)
+            extra = ("strong", {
+                "what": f"ONE batch of {bt2} problems (seed {seed0}), contiguous slices over {world} GPUs, RCCL gather of "
+                        f"every slice's results to rank 0 inside the timed region",
+                "value": S["n_conv_all"] * S["steps"] / S["elapsed"], "unit": "OCP/s",
+                "ms_per_step": 1e3 * S["elapsed"] / S["steps"], "steps": S["steps"], "warmup": 1,
+                "solved_per_sec_all_statuses": S["B_all"] * S["steps"] / S["elapsed"],
+                "converged_fraction": S["n_conv_all"] / S["B_all"] if S["B_all"] else 0.0,
+                "gather_ms_per_step": S["gather_ms"],
+                "gather_bytes": int((bt2 - S["B"]) * flops.result_bytes(S["N"])),
+                "per_rank": per_rank_list(S),
+                "speedup_over_one_rank_solving_its_weak_batch": (1e3 * elapsed / max(args.steps, 1)) / (1e3 * S["elapsed"] / S["steps"]),
+                "note": "a rank's time is bounded below by its longest problem (interior-point iterations x the "
+                        "single-problem iteration time), which does not shrink with the slice"})
+            del S, p2
+        else:
+            p2, bt2 = prepare(False, reachable=True)
+            S = measure(p2, bt2, False, args.extra_steps, 1)
+            secs2 = S["kernel_ms"] * 1e-3
+            extra = ("reachable", {
+                "what": f"{bt2} problems whose goals are reachable by construction (mpc_amd.synthetic.reachable_batch, "
+                        f"seed {seed0}), N={S['N']}: the workload on which `converged per second` means what it says",
+                "value": S["n_conv_all"] * S["steps"] / S["elapsed"], "unit": "OCP/s",
+                "ms_per_step": 1e3 * S["elapsed"] / S["steps"], "steps": S["steps"], "warmup": 1,
+                "converged_fraction": S["n_conv_all"] / S["B_all"] if S["B_all"] else 0.0,
+                "solved_per_sec_all_statuses": S["B_all"] * S["steps"] / S["elapsed"],
+                "ip_iterations_total": int(S["qp_all"]), "kernel_ms": S["kernel_ms"],
+                "frac": (S["fl"] / secs2 / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if secs2 > 0 else 0.0,
+                "frac_dense_count": (S["fl_dense"] / secs2 / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if secs2 > 0 else 0.0})
+            del S, p2
+        torch.cuda.empty_cache()
 
     if rank != 0:
         if world > 1:
@@ -312,7 +381,7 @@ def main():
         if (int(pmc["batch"]) == B and not args.obstacle and not args.reachable and args.seed is None
                 and not args.order and not (args.distinct_batches and world > 1) and not strong):
             traffic = (float(pmc["read_factor"]) * float(pmc["fetch_kib"]) + float(pmc["write_kib"])) * 1024.0
-            traffic_src = {"file": "profiles/pmc_traffic.json", "git": git_sha_of("profiles/pmc_traffic.json"),
+            traffic_src = {"file": "profiles/pmc_traffic.json", "git": pmc.get("git") or git_sha_of("profiles/pmc_traffic.json"),
                            "passes": pmc.get("source"), "measured_in_this_run": False}
     except (OSError, ValueError, KeyError):
         pass
@@ -340,8 +409,7 @@ def main():
                    "initial_guess": "host array uploaded" if args.host_guess else "computed in the solve kernel",
                    "parallelism": (f"one batch, contiguous slices x{world}, RCCL gather to rank 0" if strong
                                    else f"independent batch per GPU x{world}, no data-path collective"),
-                   "per_rank": [{"rank": i, "ms_per_step": r[0], "kernel_ms": r[1], "longest_problem_ip_iterations": int(r[2])}
-                                for i, r in enumerate(per_rank_rows)],
+                   "per_rank": per_rank_list(R),
                    **({"gather_ms_per_step": gather_ms,
                        "gather_bytes": int((B_total - B) * flops.result_bytes(N))} if strong and world > 1 else {})},
         "roofline": {
@@ -371,6 +439,9 @@ def main():
             "kernel_ms_source": "HIP events on the launch stream around each step, mean over the timed steps (rank 0)",
             "batch_io_GBs": io_bytes / secs / 1e9 if secs > 0 else 0.0},
     }
+
+    if extra:
+        line[extra[0]] = extra[1]
 
     if world == 1 and not args.no_host_to_host and B > 0:
         # the whole call as a host caller sees it: host tables in, results and counters in host memory

@@ -272,3 +272,35 @@ def test_start_inside_constraints_matches_oracle(oracle):
     assert list(got[0]) == [4, 4, 4]
     for ego, sim in pairs:
         assert find_path(ego, sim) is None
+
+
+def _bench_line(*flags):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_carries_both_stories():
+    """One run, one JSON line.  N = 1: the headline plus the workload whose goals are reachable by
+    construction.  N = 2 (rehearsed on this one GPU, collectives over gloo): the weak number plus the
+    north-star's strong-scaling block -- one batch, contiguous slices, gather to rank 0 in the timed region."""
+    small = ("--batch", "4096", "--steps", "1", "--warmup", "0", "--extra-steps", "1")
+    one = _bench_line(*small, "--cpu-sample", "512")
+    assert one["n_gpus"] == 1 and one["scaling"] == "weak" and one["dtype"] == "f64" and one["unit"] == "OCP/s"
+    assert {"roofline", "cpu_baseline", "host_to_host", "reachable"} <= set(one)
+    assert one["cpu_baseline"]["gpu_matches_cpu_on_sample"] is True
+    rb = one["reachable"]
+    assert rb["converged_fraction"] > 0.85 > one["config"]["converged_fraction"] and rb["value"] > 0 and rb["frac"] > 0
+    two = _bench_line(*small, "--gpus", "2", "--rehearse-on-one-gpu")
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and "rehearsal" in two and "reachable" not in two
+    assert two["config"]["problems_total"] == 2 * 4096
+    sb = two["strong"]
+    assert [p["problems"] for p in sb["per_rank"]] == [2048, 2048] and sb["gather_bytes"] > 0
+    assert sb["value"] > 0 and sb["ms_per_step"] > 0 and sb["gather_ms_per_step"] >= 0
+    assert abs(sb["converged_fraction"] - one["config"]["converged_fraction"]) < 1e-12      # the same 4096 problems

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 KEYS = ("X", "U", "status", "sqp_iter", "qp_iter", "cost", "res")
 
 
-def _device_solve(lib, packed, static):
+def _device_solve(lib, packed, static, setup=False):
     dev = torch.device("cuda", 0)
     B, N = packed.B, packed.N
     d_pd = torch.from_numpy(packed.pdata).to(dev)
@@ -41,9 +41,11 @@ def _device_solve(lib, packed, static):
         torch.cuda.synchronize()
         before, before_torch = torch.cuda.mem_get_info()[0], torch.cuda.memory_allocated()
         rc = lib.mpcx_solve_batch_static(C.byref(bs), C.byref(o), C.byref(rs), stream)
-        assert torch.cuda.mem_get_info()[0] == before and torch.cuda.memory_allocated() == before_torch
+        # (the set-up call on a device may: the array's address is looked up then, and the driver makes the
+        # library's device globals resident at that point)
+        assert setup or (torch.cuda.mem_get_info()[0] == before and torch.cuda.memory_allocated() == before_torch)
         torch.cuda.synchronize()
-        assert torch.cuda.mem_get_info()[0] == before
+        assert setup or torch.cuda.mem_get_info()[0] == before
     else:
         ws_bytes = lib.mpcx_workspace_bytes(B, N)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -57,7 +59,7 @@ def test_static_scratch_entry_point_matches_device_entry_point():
     lib = _lib.load_library()
     first = synthetic_batch(3000)                                     # more problems than the scratch holds at once
     second = pack_problems(*cases.obstacle_problems(40, 13.0))       # smaller, another horizon, obstacle rows
-    _device_solve(lib, synthetic_batch(8), static=True)               # set-up call: symbol lookup, code load
+    _device_solve(lib, synthetic_batch(8), static=True, setup=True)   # set-up call: symbol lookup, code load
     for packed in (first, second):
         want = _device_solve(lib, packed, static=False)
         got = _device_solve(lib, packed, static=True)
@@ -98,7 +100,7 @@ def test_static_entry_point_under_graph_capture():
     allocation) and replayed, it leaves the bits of an eager call."""
     lib = _lib.load_library()
     packed = synthetic_batch(500)
-    want = _device_solve(lib, packed, static=True)          # eager (also the set-up call on this device)
+    want = _device_solve(lib, packed, static=True, setup=True)     # eager (the set-up call when run alone)
     keep, out, bs, rs = _device_arrays(packed)
     o = _lib.default_opts(lib)
     side = torch.cuda.Stream()
