@@ -59,6 +59,10 @@
 // type, so that the callee still emits global_load / ds_read rather than flat accesses.
 typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(3))) double ldouble;
+// ... and so do the solver options (global memory, behind the problem counter in the workspace header): a
+// generic pointer would make every read of them a flat access, which the hardware may complete out of order
+// with the streaming loads around it and which the compiler therefore brackets with waits for everything
+typedef __attribute__((address_space(1))) const mpcx_opts gopts;
 
 // The reciprocals of the slacks are needed in all four sweeps of an interior-point iteration.
 // 1: computed once per iteration and kept in the workspace; 0: recomputed where needed, which
@@ -218,7 +222,7 @@ DEV double sreg(double v)
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
-DEV mpcx_opts opts_in_registers(const mpcx_opts *op)
+DEV mpcx_opts opts_in_registers(gopts *op)
 {
     mpcx_opts o;
     o.max_sqp_iter = __builtin_amdgcn_readfirstlane(op->max_sqp_iter);
@@ -944,7 +948,7 @@ DEV void stage_L(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, boo
 // allocation; arguments travel by value in registers and results come back through a
 // small per-lane LDS area `ret` ([slot][lane] doubles), never through the stack.
 template <int NH>
-__device__ __attribute__((noinline)) void sweep_L(Lane L, PC<NH> pc, const mpcx_opts *op, bool first, bool zero_u, double alpha,
+__device__ __attribute__((noinline)) void sweep_L(Lane L, PC<NH> pc, gopts *op, bool first, bool zero_u, double alpha,
                                                   ldouble *ret)
 {
     const mpcx_opts ol = opts_in_registers(op);
@@ -1585,7 +1589,7 @@ DEV void store_ric(const Lane &L, int k, bool factors, const RicOut &ro)
 }
 
 template <int NH>
-__device__ __attribute__((noinline)) void sweep_B0(Lane L, PC<NH> pc, const mpcx_opts *op, bool sp_have, int sp_mode,
+__device__ __attribute__((noinline)) void sweep_B0(Lane L, PC<NH> pc, gopts *op, bool sp_have, int sp_mode,
                                                    double sp_sigma_mu, double sp_alpha, int m_total, ldouble *ret)
 {
     const mpcx_opts ol = opts_in_registers(op);
@@ -1779,7 +1783,7 @@ DEV void stage_Bs(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, do
 }
 
 template <int NH>
-__device__ __attribute__((noinline)) void sweep_Bs(Lane L, PC<NH> pc, const mpcx_opts *op, double sigma_mu)
+__device__ __attribute__((noinline)) void sweep_Bs(Lane L, PC<NH> pc, gopts *op, double sigma_mu)
 {
     const mpcx_opts ol = opts_in_registers(op);
     const mpcx_opts &o = ol;
@@ -2044,7 +2048,7 @@ DEV void stage_F(const Lane &L, const mpcx_opts &o, const PC<NH> &pc, int k, dou
 // NS = 1: returns the affine step length, ret[0], ret[1] = S1, S2.
 // NS = 2: returns the corrector step length, ret[0] = the centring-only one.
 template <int NH, int NS>
-__device__ __attribute__((noinline)) double sweep_F(Lane L, PC<NH> pc, const mpcx_opts *op, double sigma_mu, ldouble *ret)
+__device__ __attribute__((noinline)) double sweep_F(Lane L, PC<NH> pc, gopts *op, double sigma_mu, ldouble *ret)
 {
     const mpcx_opts ol = opts_in_registers(op);
     const mpcx_opts &o = ol;
@@ -2301,7 +2305,7 @@ DEV void lds_order()
 // one block of 64 consecutive stages (k0 .. k0+63) of sweep B0; what the block above handed
 // down, and the running reductions, are read from and left in the carry words
 template <int NH, bool ONE>
-__device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, const mpcx_opts *op, bool sp_have, int sp_mode,
+__device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, gopts *op, bool sp_have, int sp_mode,
                                                         double sp_sigma_mu, double sp_alpha, int k0, ldouble *ret)
 {
     COOP_UNPACK(NH);
@@ -2424,7 +2428,7 @@ __device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, const mpcx_
 }
 
 template <int NH>
-DEV void coop_B0(const Lane &C, const PC<NH> &pc, const mpcx_opts *op, const Step &sp, int m_total, ldouble *ret)
+DEV void coop_B0(const Lane &C, const PC<NH> &pc, gopts *op, const Step &sp, int m_total, ldouble *ret)
 {
     const int N = __builtin_amdgcn_readfirstlane(C.N);      // (the same in every lane: loop counts in scalar registers)
     ldouble *carry = ret - threadIdx.x + 5 * 64;
@@ -2445,7 +2449,7 @@ DEV void coop_B0(const Lane &C, const PC<NH> &pc, const mpcx_opts *op, const Ste
 }
 
 template <int NH, bool ONE>
-__device__ __attribute__((noinline)) void coop_Bs(COOP_PARAMS, const mpcx_opts *op, double sigma_mu)
+__device__ __attribute__((noinline)) void coop_Bs(COOP_PARAMS, gopts *op, double sigma_mu)
 {
     COOP_UNPACK(NH);
     (void)op;
@@ -2490,7 +2494,7 @@ __device__ __attribute__((noinline)) void coop_Bs(COOP_PARAMS, const mpcx_opts *
 }
 
 template <int NH, int NS, bool ONE>
-__device__ __attribute__((noinline)) double coop_F(COOP_PARAMS, const mpcx_opts *op, double sigma_mu, ldouble *ret)
+__device__ __attribute__((noinline)) double coop_F(COOP_PARAMS, gopts *op, double sigma_mu, ldouble *ret)
 {
     COOP_UNPACK(NH);
     const mpcx_opts ol = opts_in_registers(op);
@@ -2580,7 +2584,7 @@ static_assert(BR_N <= CY_N, "burst results fit the carry words");
 static_assert(MPCX_STORE_RECIP == 0, "the resident burst keeps the slack reciprocals in registers itself");
 
 template <int NH>
-__device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opts *op, int sp_have_mode,
+__device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, gopts *op, int sp_have_mode,
                                                      double sp_sigma_mu, double sp_alpha, int m_total, int qit_max,
                                                      ldouble *ret)
 {
@@ -2909,7 +2913,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, const mpcx_opt
 // sweep L has no recursion: every stage is linearised at its own (new) state, which its lane
 // forms from the stage's own iterate and step exactly as the stage before would have
 template <int NH, bool ONE>
-__device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, const mpcx_opts *op, bool first, bool zero_u, double alpha, ldouble *ret)
+__device__ __attribute__((noinline)) void coop_L(COOP_PARAMS, gopts *op, bool first, bool zero_u, double alpha, ldouble *ret)
 {
     typedef Map<NH> M;
     COOP_UNPACK(NH);
@@ -3040,11 +3044,12 @@ __device__ __attribute__((noinline)) void coop_M(COOP_PARAMS, double alpha, ldou
 // would then save and restore over a hundred registers through scratch memory on every call)
 template <int NH>
 __global__ void __launch_bounds__(64) __attribute__((disable_tail_calls))
-mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
+mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
                 int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots, unsigned deal, int burst_few,
                 double hold_alpha, int hold_extra, int boost_mul)
 {
-    const mpcx_opts &o = *op;
+    const mpcx_opts &o = *op_generic;
+    gopts *op = (gopts *)op_generic;      // what the sweeps are handed
     typedef Map<NH> M;
     const int N = in.N;
     const unsigned B = (unsigned)in.B;
