@@ -1,4 +1,6 @@
-// The backward Riccati factorisation of ONE problem (nx = 5, nu = 2, N stages) by one wavefront, two ways:
+// The backward Riccati factorisation of ONE problem (nx = 5, nu = 2, N stages) by one wavefront, three ways
+// (SPREAD2, which keeps P(k+1) out of the scalar registers and pays three LDS-crossbar round trips a step
+// instead, is described at its kernel):
 //
 //   PIPE    the lane pipeline of the shipped single-problem mode: lane k owns stage k, every step every
 //           lane recomputes its stage from what the lane above produced the step before (DPP wave_shl:1),
@@ -304,6 +306,229 @@ __global__ void __launch_bounds__(64) k_spread(const StageIn *stages, double hB,
     if (lane == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// SPREAD2.  Lane 8 g + c: group g = 0..4 owns row NU+g of M (an x row), groups 5, 6 own rows 0, 1 (the u
+// rows); c is the column of M.  Per step:
+//   A  every lane of group g < 5 takes row g of P(k+1) from the lanes (g, NU+j) of its own group
+//      (ds_swizzle, pattern fixed at compile time) and forms entry (g, c) of P [B A] (5 multiply-adds);
+//      the same row gives entry g of P(k+1) rb;
+//   B  column c of P [B A] is gathered from the lanes (0..4, c) (ds_bpermute) and the lane forms its entry
+//      of M (5 multiply-adds);
+//   C  the three entries of M_uu go to scalar registers, the LDL' is formed in every lane; meanwhile the
+//      lane gathers M[r][0..1] of its row (swizzle), of the row that belongs to its column, and the entry of
+//      M mirrored at the diagonal (bpermute);
+//   D  the lanes (g, NU+j), g, j < 5, form entry (g, j) of P(k): below and on the diagonal from their own
+//      entry of M, above it as the mirror entry (j, g) -- the same operations on the same operands the
+//      lane (j, g) performs, so row g of P(k) is complete in group g for the next step.
+// Staging record (doubles): [0,35) [B A] by column; [35,42) diagonal of the barrier Hessian; 42 hxy; 43 zero;
+// [44,49) rb.  Results of a stage into its record: [0,5) K row 0, [5,10) K row 1, 10 l10, 11 d0, 12 d1,
+// [13,18) P(k+1) rb.
+// ---------------------------------------------------------------------------------------------------
+#define REC2 50
+
+template <int PAT>
+DEV double swz(double v)
+{
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), PAT);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), PAT);
+    return __hiloint2double(hi, lo);
+}
+DEV double bperm(int addr, double v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// BitMode swizzle: lane' = ((lane & and) | or) ^ xor inside each half of the wavefront; and = 0x18 keeps the
+// group, or = the column to read from
+#define SWZ_GROUP_COL(col) ((0x18) | ((col) << 5))
+
+template <int CH>
+__global__ void __launch_bounds__(64) k_spread2(const StageIn *stages, const double *rbs, double hB, int N, int reps,
+                                                StageOut *out, double *prb_out, double *P0, long long *cycles)
+{
+    __shared__ double rec[CH * REC2 + 8];
+    const int lane = (int)threadIdx.x;
+    const int g = lane >> 3, c = lane & 7;
+    const int r = (g < NX) ? NU + g : (g - NX);            // row of M this group owns (groups 5, 6: rows 0, 1; group 7: none)
+    const bool ent = (g < NZ) && (c < NZ);
+    const int rr = ent ? r : 0, cc = ent ? c : 0, gg = ent ? g : 5;
+    const StageIn *mine = stages + (size_t)blockIdx.x * 64;
+    const StageIn in = mine[lane];
+    double rb[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) rb[i] = rbs[((size_t)blockIdx.x * 64 + lane) * NX + i];
+    StageOut ro = {};
+    double prb[NX] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    const unsigned off_c = 8u * 5u * (unsigned)cc, off_r = 8u * 5u * (unsigned)rr;
+    const unsigned off_h = 8u * (unsigned)((rr == cc) ? 35 + rr : (rr == 3 && cc == 2) ? 42 : 43);
+    const bool pl = ent && gg < NX && cc >= NU;             // the lane holds an entry of P
+    const int j = pl ? cc - NU : 0;                         // ... entry (gg, j)
+    const bool lower = gg >= j;
+    // cross-lane sources
+    const int a_col = 4 * cc;                                // column gather: lanes (i, c), + 32 i
+    const int a_row0 = 4 * (8 * (pl ? j : 0) + 0);           // M[NU+j][0], M[NU+j][1]: lanes (j, 0), (j, 1)
+    const int a_mirror = 4 * (8 * (pl ? j : 0) + NU + (pl ? gg : 0));      // M[NU+j][NU+g]: lane (j, NU+g)
+    const unsigned spare = 8u * (unsigned)(CH * REC2);
+    double pnew = 0.0;
+    long long t0 = __builtin_amdgcn_s_memtime();
+    for (int rep = 0; rep < reps; ++rep) {
+        {
+            double e = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NX; ++jj) {
+                    const double v = rdlane(ht_entry(in, (i >= jj) ? i : jj, (i >= jj) ? jj : i), N);
+                    e = (pl && gg == i && j == jj) ? v : e;
+                }
+            pnew = e;
+        }
+        for (int khi = N - 1; khi >= 0; khi -= CH) {
+            const int klo = (khi - CH + 1 > 0) ? khi - CH + 1 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= klo && lane <= khi) {
+                double *w = rec + (lane - klo) * REC2;
+                const double *ab = in.ab;
+                w[0] = ab[8];  w[1] = ab[9];  w[2] = ab[10]; w[3] = hB;  w[4] = 0.0;
+                w[5] = ab[11]; w[6] = ab[12]; w[7] = ab[13]; w[8] = 0.0; w[9] = hB;
+                w[10] = 1.0; w[11] = 0.0; w[12] = 0.0; w[13] = 0.0; w[14] = 0.0;
+                w[15] = 0.0; w[16] = 1.0; w[17] = 0.0; w[18] = 0.0; w[19] = 0.0;
+                w[20] = ab[0]; w[21] = ab[3]; w[22] = 1.0; w[23] = 0.0; w[24] = 0.0;
+                w[25] = ab[1]; w[26] = ab[4]; w[27] = ab[6]; w[28] = 1.0; w[29] = 0.0;
+                w[30] = ab[2]; w[31] = ab[5]; w[32] = ab[7]; w[33] = 0.0; w[34] = 1.0;
+#pragma unroll
+                for (int q = 0; q < NZ; ++q) w[35 + q] = (q == 2) ? in.Ht[2] + in.hxx : (q == 3) ? in.Ht[3] + in.hyy : in.Ht[q];
+                w[42] = in.hxy;
+                w[43] = 0.0;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) w[44 + i] = rb[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const char *base = (const char *)rec + (size_t)(khi - klo) * REC2 * 8;
+            double bc[NX], br[NX], ht, rbk[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                bc[i] = *(const double *)(base + off_c + 8 * i); br[i] = *(const double *)(base + off_r + 8 * i);
+                rbk[i] = *(const double *)(base + 8 * (44 + i));
+            }
+            ht = *(const double *)(base + off_h);
+            for (int k = khi; k >= klo; --k) {
+                double nbc[NX], nbr[NX], nht, nrb[NX];
+                const char *nb = (k > klo) ? base - REC2 * 8 : base;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    nbc[i] = *(const double *)(nb + off_c + 8 * i); nbr[i] = *(const double *)(nb + off_r + 8 * i);
+                    nrb[i] = *(const double *)(nb + 8 * (44 + i));
+                }
+                nht = *(const double *)(nb + off_h);
+                // A: row g of P(k+1), from the lanes (g, NU + jj) of the lane's own group
+                const double p0 = swz<SWZ_GROUP_COL(2)>(pnew), p1 = swz<SWZ_GROUP_COL(3)>(pnew), p2 = swz<SWZ_GROUP_COL(4)>(pnew),
+                             p3 = swz<SWZ_GROUP_COL(5)>(pnew), p4 = swz<SWZ_GROUP_COL(6)>(pnew);
+                double pba = p0 * bc[0];
+                pba = fma(p1, bc[1], pba); pba = fma(p2, bc[2], pba); pba = fma(p3, bc[3], pba); pba = fma(p4, bc[4], pba);
+                double pr = p0 * rbk[0];
+                pr = fma(p1, rbk[1], pr); pr = fma(p2, rbk[2], pr); pr = fma(p3, rbk[3], pr); pr = fma(p4, rbk[4], pr);
+                // B: column c of P [B A] from the lanes (0..4, c), then the lane's entry of M
+                const int plo = __double2loint(pba), phi = __double2hiint(pba);
+                double m = ht;
+#define COLTERM(i_)                                                                                                    \
+                m = fma(br[i_], __hiloint2double(__builtin_amdgcn_ds_bpermute(a_col + 32 * (i_), phi),                  \
+                                                 __builtin_amdgcn_ds_bpermute(a_col + 32 * (i_), plo)), m);
+                COLTERM(0) COLTERM(1) COLTERM(2) COLTERM(3) COLTERM(4)
+#undef COLTERM
+                // C: LDL' of M_uu in every lane; the exchanges of phase D meanwhile
+                const double m00 = rdlane(m, 8 * 5 + 0), m10 = rdlane(m, 8 * 6 + 0), m11 = rdlane(m, 8 * 6 + 1);
+                const double mr0 = swz<SWZ_GROUP_COL(0)>(m), mr1 = swz<SWZ_GROUP_COL(1)>(m);      // M[NU+g][0..1]
+                const double mc0 = bperm(a_row0, m), mc1 = bperm(a_row0 + 4, m);                   // M[NU+j][0..1]
+                const double mT = bperm(a_mirror, m);                                              // M[NU+j][NU+g]
+                const double d0 = 1.0 / m00;
+                const double l10 = m10 * d0;
+                const double d1 = 1.0 / fma(-l10, m10, m11);
+                // D: entry (g, j) of P(k): feedback column of the smaller index, row of the larger
+                const double y0 = lower ? mc0 : mr0, y1r = lower ? mc1 : mr1;
+                const double x0 = lower ? mr0 : mc0, x1 = lower ? mr1 : mc1, mm = lower ? m : mT;
+                const double y1 = fma(-l10, y0, y1r);
+                const double z0 = y0 * d0, z1 = y1 * d1;
+                const double s0 = fma(-l10, z1, z0);
+                const double k0 = -s0, k1 = -z1;
+                const double e = fma(x0, k0, mm);
+                pnew = fma(x1, k1, e);
+                // results of stage k into its record: K column j from the diagonal lanes, the pivots from lane 0,
+                // P(k+1) rb from the lanes (i, 0)
+                {
+                    char *ob = (char *)rec + (size_t)(k - klo) * REC2 * 8;
+                    const unsigned back = (unsigned)((k - klo) * REC2 * 8);
+                    const bool dg = pl && gg == j;
+                    const unsigned o0 = dg ? 8u * (unsigned)j : (lane == 0) ? 8u * 10u : spare - back;
+                    const unsigned o1 = dg ? 8u * (unsigned)(5 + j) : (lane == 0) ? 8u * 11u : spare - back;
+                    const unsigned o2 = (ent && gg < NX && cc == 0) ? 8u * (unsigned)(13 + gg) : (lane == 1) ? 8u * 12u : spare - back;
+                    *(double *)(ob + o0) = dg ? k0 : l10;
+                    *(double *)(ob + o1) = dg ? k1 : d0;
+                    *(double *)(ob + o2) = (lane == 1) ? d1 : pr;
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { bc[i] = nbc[i]; br[i] = nbr[i]; rbk[i] = nrb[i]; }
+                ht = nht;
+                base = nb;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= klo && lane <= khi) {
+                const double *w = rec + (lane - klo) * REC2;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { ro.K[0][i] = w[i]; ro.K[1][i] = w[5 + i]; prb[i] = w[13 + i]; }
+                ro.l10 = w[10]; ro.d0 = w[11]; ro.d1 = w[12];
+            }
+        }
+        pnew = fresh(pnew);
+    }
+    long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane <= N) {
+        out[(size_t)blockIdx.x * 64 + lane] = ro;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) prb_out[((size_t)blockIdx.x * 64 + lane) * NX + i] = prb[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int jj = 0; jj <= i; ++jj)
+            if (lane == 8 * i + (NU + jj)) P0[(size_t)blockIdx.x * 15 + tri(i, jj)] = pnew;
+    if (lane == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+// P(k+1) rb of every stage by the lane pipeline's formula (reference for SPREAD2's product)
+__global__ void __launch_bounds__(64) k_pipe_prb(const StageIn *stages, const double *rbs, double hB, int N, double *prb_out)
+{
+    const int kj = (int)threadIdx.x;
+    const StageIn in = stages[(size_t)blockIdx.x * 64 + kj];
+    StageOut ro = {};
+    double Po[15];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Po[tri(i, j)] = (kj == N) ? ht_entry(in, i, j) : 0.0;
+    for (int s = 0; s < N; ++s) {
+        double Pi[15];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) Pi[i] = lane_above0(Po[i]);
+        if (kj < N) ric_stage(in, hB, Pi, Po, ro);
+    }
+    double Pi[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) Pi[i] = lane_above0(Po[i]);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        double acc = psym(Pi, i, 0) * rbs[((size_t)blockIdx.x * 64 + kj) * NX + 0];
+#pragma unroll
+        for (int j = 1; j < NX; ++j) acc = fma(psym(Pi, i, j), rbs[((size_t)blockIdx.x * 64 + kj) * NX + j], acc);
+        if (kj < N) prb_out[((size_t)blockIdx.x * 64 + kj) * NX + i] = acc;
+    }
+}
+
 static double urand(unsigned long long &s)
 {
     s = s * 6364136223846793005ull + 1442695040888963407ull;
@@ -328,6 +553,11 @@ int main(int argc, char **argv)
         const double w = pow(10.0, 8.0 * urand(seed) - 4.0), jx = urand(seed) - 0.5, jy = urand(seed) - 0.5;
         s.hxx = w * jx * jx; s.hxy = w * jy * jx; s.hyy = w * jy * jy;
     }
+    std::vector<double> rbs(st.size() * NX);
+    for (auto &v : rbs) v = 1e-2 * (urand(seed) - 0.5);
+    double *d_rb, *d_prb1, *d_prb2;
+    hipMalloc(&d_rb, rbs.size() * 8); hipMalloc(&d_prb1, rbs.size() * 8); hipMalloc(&d_prb2, rbs.size() * 8);
+    hipMemcpy(d_rb, rbs.data(), rbs.size() * 8, hipMemcpyHostToDevice);
     StageIn *d_st; StageOut *d_o1, *d_o2; double *d_p1, *d_p2; long long *d_cy;
     hipMalloc(&d_st, st.size() * sizeof(StageIn));
     hipMalloc(&d_o1, st.size() * sizeof(StageOut)); hipMalloc(&d_o2, st.size() * sizeof(StageOut));
@@ -380,6 +610,32 @@ int main(int argc, char **argv)
     }
     RUN_SPREAD(64)
     RUN_SPREAD(13)
+    // second variant, with P(k+1) rb riding along
+    hipMemset(d_prb1, 0, rbs.size() * 8);
+    hipLaunchKernelGGL(k_pipe_prb, dim3(WG), dim3(64), 0, 0, d_st, d_rb, hB, N, d_prb1);
+    std::vector<double> q1(rbs.size()), q2(rbs.size());
+    hipMemcpy(q1.data(), d_prb1, rbs.size() * 8, hipMemcpyDeviceToHost);
+#define RUN_SPREAD2(CH_)                                                                                     \
+    for (int pass = 0; pass < 2; ++pass) {                                                                   \
+        hipMemset(d_o2, 0, st.size() * sizeof(StageOut));                                                    \
+        hipMemset(d_prb2, 0, rbs.size() * 8);                                                                \
+        hipEventRecord(e0);                                                                                  \
+        hipLaunchKernelGGL(k_spread2<CH_>, dim3(WG), dim3(64), 0, 0, d_st, d_rb, hB, N, reps, d_o2, d_prb2, d_p2, d_cy); \
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);                       \
+        if (pass) {                                                                                          \
+            report("SPREAD2, " #CH_ " stages staged", ms);                                                   \
+            ok = check("SPREAD2, " #CH_ " stages staged") && ok;                                             \
+            hipMemcpy(q2.data(), d_prb2, rbs.size() * 8, hipMemcpyDeviceToHost);                             \
+            size_t badq = 0;                                                                                 \
+            for (int w = 0; w < WG; ++w)                                                                     \
+                for (int k = 0; k < N; ++k)                                                                  \
+                    if (memcmp(&q1[((size_t)w * 64 + k) * NX], &q2[((size_t)w * 64 + k) * NX], NX * 8) != 0) ++badq; \
+            printf("%-28s P(k+1) rb: %zu stages differ\n", "", badq);                                       \
+            ok = ok && badq == 0;                                                                            \
+        }                                                                                                    \
+    }
+    RUN_SPREAD2(64)
+    RUN_SPREAD2(11)
     if (hipDeviceSynchronize() != hipSuccess) { printf("HIP error\n"); return 2; }
     return ok ? 0 : 1;
 }
