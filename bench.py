@@ -417,7 +417,8 @@ def main():
             # workspace, so the kernel is bound by the bytes it moves, not by the FP64 units
             "bound": "hbm",
             "bound_detail": "hbm_workspace" if traffic else "hbm_workspace (no committed counter pass for this batch)",
-            # the FP64 fraction the metric asks for, on the structure-exploiting operation count
+            # the FP64 fraction the metric asks for, on the structure-exploiting operation count (estimated
+            # closed forms; frac_dense_count below is on the count taken from an operation-counting build)
             "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS,
             "flops_per_launch": fl, "flops_constants": flops.constants(sparse=True),

@@ -2,7 +2,8 @@
 
 Two sets of per-stage constants (FMA = 2, + - * / = 1, sin and cos = 1 each):
 
-* structure-exploiting (the set the roofline fraction is quoted on): the closed forms for
+* structure-exploiting (the set the roofline fraction is quoted on; ESTIMATED: rounded closed forms, not
+  counted on any executable -- the counted figure is the dense one below): the closed forms for
   nx = 5, nu = 2 -- interior-point iteration 1.5e3 = Riccati factorisation
   7/3 nx^3 + 4 nx^2 nu + 2 nx nu^2 + nu^3/3 = 534, two substitutions (predictor, corrector)
   2 (8 nx^2 + 8 nx nu + 2 nu^2) = 576, barrier Hessian / right-hand sides / step lengths /
@@ -24,9 +25,10 @@ def constants(sparse=True):
     """The per-stage constants as a dict (for the benchmark line)."""
     if sparse:
         return {"per_stage_linearisation": F_LIN, "per_stage_qp_solve": F_INIT, "per_stage_ip_iteration": F_IPM,
-                "kind": "closed forms for nx=5, nu=2 exploiting the sparsity of the sensitivities"}
+                "kind": "closed forms for nx=5, nu=2 exploiting the sparsity of the sensitivities",
+                "estimated": True}
     return {"per_stage_linearisation": F_LIN_DENSE, "per_stage_qp_solve": F_INIT_DENSE,
-            "per_stage_ip_iteration": F_IPM_DENSE, "kind": "counted on the dense CPU restatement"}
+            "per_stage_ip_iteration": F_IPM_DENSE, "kind": "counted on the dense CPU restatement", "estimated": False}
 
 
 def algorithmic_flops(status, sqp_iter, qp_iter, N, sparse=False):

@@ -4,7 +4,7 @@ set -u
 mkdir -p gpurun_out/knob
 run() {
   tag=$1; shift
-  env "$@" timeout -k 10 150 python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-host-to-host > gpurun_out/knob/$tag.json 2> gpurun_out/knob/$tag.err || return 1
+  env "$@" timeout -k 10 150 python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-host-to-host --no-extra > gpurun_out/knob/$tag.json 2> gpurun_out/knob/$tag.err || return 1
   python3 -c "import json; d=json.loads(open('gpurun_out/knob/$tag.json').read().strip().splitlines()[-1]); print('$tag', round(d['ms_per_step'],1))"
 }
 for round in 1 2 3; do

@@ -7,7 +7,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for B in "$@"; do
   timeout -s KILL 120 rocprofv3 --pmc SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES \
-    --output-format csv -d "$OUT/b$B" -- python3 bench.py --batch "$B" --steps 1 --warmup 0 --cpu-sample 0 --no-host-to-host > "$OUT/b$B.log" 2>&1 || exit 1
+    --output-format csv -d "$OUT/b$B" -- python3 bench.py --batch "$B" --steps 1 --warmup 0 --cpu-sample 0 --no-host-to-host --no-extra > "$OUT/b$B.log" 2>&1 || exit 1
 done
 python3 - "$OUT" "$@" <<'PY'
 import csv, glob, sys, collections

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() {
   name=$1; shift
   timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- \
-    python3 bench.py --batch "$BATCH" --steps 1 --warmup 0 --cpu-sample 0 --no-host-to-host > "$OUT/$name.log" 2>&1 || return 1
+    python3 bench.py --batch "$BATCH" --steps 1 --warmup 0 --cpu-sample 0 --no-host-to-host --no-extra > "$OUT/$name.log" 2>&1 || return 1
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU &&
 run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU &&

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for B in "$@"; do
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout -s KILL 120 rocprofv3 --pmc $C --output-format csv -d "$OUT/b${B}_$C" -- \
-      python3 bench.py --batch "$B" --steps 1 --warmup 0 --cpu-sample 0 --no-host-to-host > "$OUT/b${B}_$C.log" 2>&1 || exit 1
+      python3 bench.py --batch "$B" --steps 1 --warmup 0 --cpu-sample 0 --no-host-to-host --no-extra > "$OUT/b${B}_$C.log" 2>&1 || exit 1
   done
 done
 python3 - "$OUT" "$@" <<'PY'

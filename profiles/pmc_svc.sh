@@ -8,7 +8,7 @@ for s in 4 16; do
   export MPCX_SVC_MIN=$s
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/s${s}_$c" -- \
-      python3 bench.py --batch 1000000 --steps 1 --warmup 0 --cpu-sample 0 --no-host-to-host > "$OUT/s${s}_$c.log" 2>&1 || exit 1
+      python3 bench.py --batch 1000000 --steps 1 --warmup 0 --cpu-sample 0 --no-host-to-host --no-extra > "$OUT/s${s}_$c.log" 2>&1 || exit 1
   done
 done
 python3 - "$OUT" <<'PY'
