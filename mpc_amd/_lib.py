@@ -60,7 +60,8 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # (MPCX_LIB_PATH: another build of the library, for A/B runs of diagnostic builds)
+    p = path or os.environ.get("MPCX_LIB_PATH") or LIB_PATH
     if not os.path.exists(p):
         raise MpcxError(
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

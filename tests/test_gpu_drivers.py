@@ -293,7 +293,8 @@ def test_bench_line_carries_both_stories():
     small = ("--batch", "4096", "--steps", "1", "--warmup", "0", "--extra-steps", "1")
     one = _bench_line(*small, "--cpu-sample", "512")
     assert one["n_gpus"] == 1 and one["scaling"] == "weak" and one["dtype"] == "f64" and one["unit"] == "OCP/s"
-    assert {"roofline", "cpu_baseline", "host_to_host", "reachable"} <= set(one)
+    assert {"roofline", "cpu_baseline", "host_to_host", "reachable", "two_launches_in_flight"} <= set(one)
+    assert one["two_launches_in_flight"]["same_converged_count"] is True
     assert one["cpu_baseline"]["gpu_matches_cpu_on_sample"] is True
     rb = one["reachable"]
     assert rb["converged_fraction"] > 0.85 > one["config"]["converged_fraction"] and rb["value"] > 0 and rb["frac"] > 0
