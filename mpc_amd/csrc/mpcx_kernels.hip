@@ -2105,6 +2105,14 @@ __device__ unsigned long long g_stamps[2048][N_STAMP];
         if (g_stamps[blockIdx.x][2 * (slot)] == 0) g_stamps[blockIdx.x][2 * (slot)] = wall_clock64(); \
     } while (0)
 #define MARK_LAST(slot) do { g_stamps[blockIdx.x][2 * (slot)] = wall_clock64(); } while (0)
+// time and age when the wavefront first starts a burst of a problem at least `thr` iterations old (two words)
+#define MARK_AGE(word, thr, age)                                                           \
+    do {                                                                                   \
+        if ((age) >= (thr) && g_stamps[blockIdx.x][word] == 0) {                           \
+            g_stamps[blockIdx.x][word] = wall_clock64();                                   \
+            g_stamps[blockIdx.x][(word) + 1] = (unsigned long long)(age);                  \
+        }                                                                                  \
+    } while (0)
 // cycles of a part of a non-inlined function (slots 16..19)
 #define SUB_BEGIN() unsigned long long sub_t0 = __builtin_amdgcn_s_memtime()
 #define SUB_END(slot)                                                                  \
@@ -2116,6 +2124,7 @@ __device__ unsigned long long g_stamps[2048][N_STAMP];
 #else
 #define MARK(slot) ((void)0)
 #define MARK_LAST(slot) ((void)0)
+#define MARK_AGE(word, thr, age) ((void)0)
 #define STAMP_DECL() ((void)0)
 #define STAMP_BEGIN() ((void)0)
 #define STAMP(slot, pred) ((void)0)
@@ -2583,6 +2592,177 @@ enum { BR_STATE = 0, BR_STATUS, BR_ADD_TOTAL, BR_ADD_SQP, BR_QIT, BR_HAVE, BR_MO
 static_assert(BR_N <= CY_N, "burst results fit the carry words");
 static_assert(MPCX_STORE_RECIP == 0, "the resident burst keeps the slack reciprocals in registers itself");
 
+// ---------------------------------------------------------------------------
+// The backward Riccati recursion of a burst -- factors and the affine backward substitution -- with the
+// algebra of ONE stage spread over the lanes instead of a lane pipeline over the stages.
+//
+// The lane pipelines execute a stage's ~390 instructions in every lane for one useful lane a step.  Here the
+// stages are taken in turn, N down to 0, and lane 8 r + c, r < 7, owns entry (r, c) of
+// M = Ht + [B A]' P(k+1) [B A] for c < 7 and entry r of the right-hand side m = gt + [B A]' (p(k+1) + P(k+1) rb)
+// for c = 7: P(k+1) and p(k+1) travel as 20 wave-uniform values (v_readlane), every lane forms its column of
+// P(k+1) [B A] (the right-hand-side lanes: P(k+1) rb, then + p(k+1)) and its entry with five multiply-adds
+// each, every lane factorises the 2 x 2 input block itself, and one multiply-add pair gives entry (r, c) of
+// P(k) = M_xx + M_xu K in the entry lanes and entry r of p(k) = m_x + K' m_u in the right-hand-side lanes (the
+// same two instructions on other exchange partners).  Every number is produced by the operations of
+// stage_B0_ric() in their order: the dense chains here contain the pattern chains there, and a multiplication
+// by a structural 1 or an addition of a structural 0 product leaves a finite number as it is.
+//
+// The operands of a stage are uniform per step, so they come from LDS: the stage's own lane writes a record
+// of SPR_REC doubles ([0,14) the pattern entries of A and B; 14 hB; 15 zero; 16 one; [17,24) the diagonal of the
+// barrier Hessian, the (x, y) block's added; 24 its off-diagonal entry; [25,30) rb; [30,37) gt), SPR_CH stages at
+// a time, and takes the results back from it ([0,5) K row 0; [5,10) K row 1; 10 l10; 11, 12 the reciprocal
+// pivots; 13, 14 the input part of the right-hand side).  `stg` is the wavefront's staging area of
+// SPR_CH * SPR_REC + 1 doubles.  The complementarity sum rides along as before, one pipeline step per stage.
+// ---------------------------------------------------------------------------
+#define SPR_REC 37
+#define SPR_CH 25
+#define SPR_EXTRA 704      // doubles of LDS per wavefront beyond the result slots and carry words, which the staging area also covers
+static_assert(SPR_CH * SPR_REC + 1 <= 6 * 64 + SPR_EXTRA, "staging area");
+
+DEV int spr_word(int c, int j)      // word of entry (j, c) of [B A | rb] in a staging record
+{
+    switch (c) {
+    case 0: return (j == 0) ? 8 : (j == 1) ? 9 : (j == 2) ? 10 : (j == 3) ? 14 : 15;
+    case 1: return (j == 0) ? 11 : (j == 1) ? 12 : (j == 2) ? 13 : (j == 3) ? 15 : 14;
+    case 2: return (j == 0) ? 16 : 15;
+    case 3: return (j == 1) ? 16 : 15;
+    case 4: return (j == 0) ? 0 : (j == 1) ? 3 : (j == 2) ? 16 : 15;
+    case 5: return (j == 0) ? 1 : (j == 1) ? 4 : (j == 2) ? 6 : (j == 3) ? 16 : 15;
+    case 6: return (j == 0) ? 2 : (j == 1) ? 5 : (j == 2) ? 7 : (j == 3) ? 15 : 16;
+    default: return 25 + j;
+    }
+}
+DEV double spr_perm(int addr, double v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+typedef __attribute__((address_space(3))) char lchar;
+
+DEV void burst_ric_spread(const B0Out &t, double hB, int N, ldouble *stg, RicOut &ro, double &sum)
+{
+    const int lane = (int)threadIdx.x;
+    const int r = lane >> 3, c = lane & 7;
+    const bool ent = r < NZ;
+    const bool rhs = ent && c == 7;
+    const int rr = ent ? r : 0, cc = ent ? c : 0;      // (lanes without an entry run along on entry (0, 0))
+    unsigned oc[NX], orr[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { oc[j] = 8u * (unsigned)spr_word(cc, j); orr[j] = 8u * (unsigned)spr_word(rr, j); }
+    const unsigned off_h = (cc == 7) ? 8u * (unsigned)(30 + rr)
+                                     : 8u * (unsigned)((rr == cc) ? 17 + rr : (rr == 3 && cc == 2) ? 24 : 15);
+    // where a lane's results of a step go in the record: the diagonal lanes (NU+j, NU+j) have column j of K,
+    // lane 0 the pivots, the lanes (0, 7), (1, 7) the input part of the right-hand side; the rest a spare word
+    const bool diag = ent && cc < 7 && rr == cc && rr >= NU;
+    const bool kvl = rhs && rr < NU;
+    const int spare = SPR_CH * SPR_REC;
+    const int oA = diag ? (cc - NU) : (lane == 0) ? 10 : kvl ? 13 + rr : -1;
+    const int oB = diag ? (5 + cc - NU) : (lane == 0) ? 11 : -1;
+    // exchange partners.  Entry lanes: M[r][0], M[r][1] of the row and M[c][0], M[c][1] of the column.
+    // Right-hand-side lanes: m[0], m[1], and M[r][0], M[r][1] of the row
+    const int src_r0 = 4 * (rhs ? 8 * 0 + 7 : 8 * rr + 0), src_r1 = 4 * (rhs ? 8 * 1 + 7 : 8 * rr + 1);
+    const int src_c0 = 4 * (rhs ? 8 * rr + 0 : 8 * cc + 0), src_c1 = 4 * (rhs ? 8 * rr + 1 : 8 * cc + 1);
+    // P(N), p(N): the barrier Hessian and the gradient of the last stage, from its lane
+    double pnew = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double e = 0.0;
+            if (i == j) e = (i == 0) ? t.Ht[2] + t.hxx : (i == 1) ? t.Ht[3] + t.hyy : t.Ht[NU + i];
+            else if (i == 1 && j == 0) e = t.hxy;
+            const double v = bcast(e, N);
+            pnew = (rr == NU + i && cc == NU + j) ? v : pnew;
+        }
+        const double g = bcast(t.gt[NU + i], N);
+        pnew = (rr == NU + i && cc == 7) ? g : pnew;
+    }
+    for (int khi = N - 1; khi >= 0; khi -= SPR_CH) {
+        const int klo = (khi - SPR_CH + 1 > 0) ? khi - SPR_CH + 1 : 0;
+        lds_order();
+        if (lane >= klo && lane <= khi) {
+            ldouble *w = stg + (lane - klo) * SPR_REC;
+            w[0] = t.ab.a02; w[1] = t.ab.a03; w[2] = t.ab.a04; w[3] = t.ab.a12; w[4] = t.ab.a13; w[5] = t.ab.a14;
+            w[6] = t.ab.a23; w[7] = t.ab.a24; w[8] = t.ab.b00; w[9] = t.ab.b10; w[10] = t.ab.b20; w[11] = t.ab.b01;
+            w[12] = t.ab.b11; w[13] = t.ab.b21;
+            w[14] = hB; w[15] = 0.0; w[16] = 1.0;
+#pragma unroll
+            for (int q = 0; q < NZ; ++q) w[17 + q] = (q == 2) ? t.Ht[2] + t.hxx : (q == 3) ? t.Ht[3] + t.hyy : t.Ht[q];
+            w[24] = t.hxy;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) w[25 + i] = t.rb[i];
+#pragma unroll
+            for (int q = 0; q < NZ; ++q) w[30 + q] = t.gt[q];
+        }
+        lds_order();
+        const lchar *base = (const lchar *)stg + (khi - klo) * SPR_REC * 8;
+        double bc[NX], br[NX], ht;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { bc[i] = *(const ldouble *)(base + oc[i]); br[i] = *(const ldouble *)(base + orr[i]); }
+        ht = *(const ldouble *)(base + off_h);
+        for (int k = khi; k >= klo; --k) {
+            // the operands of the next stage are fetched while this one computes
+            double nbc[NX], nbr[NX], nht;
+            const lchar *nb = (k > klo) ? base - SPR_REC * 8 : base;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { nbc[i] = *(const ldouble *)(nb + oc[i]); nbr[i] = *(const ldouble *)(nb + orr[i]); }
+            nht = *(const ldouble *)(nb + off_h);
+            sum = lane_above<true>(sum, 0.0) + t.ssum;
+            double P[15], pn[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+#pragma unroll
+                for (int j = 0; j <= i; ++j) P[tri(i, j)] = bcast(pnew, 8 * (NU + i) + (NU + j));
+                pn[i] = bcast(pnew, 8 * (NU + i) + 7);
+            }
+            double pba[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double acc = psym(P, i, 0) * bc[0];
+#pragma unroll
+                for (int j = 1; j < NX; ++j) acc = fma(psym(P, i, j), bc[j], acc);
+                pba[i] = (rhs ? pn[i] : -0.0) + acc;      // (adding -0 changes no number)
+            }
+            double m = ht;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) m = fma(br[i], pba[i], m);
+            const double m00 = bcast(m, 0), m10 = bcast(m, 8), m11 = bcast(m, 9);
+            const double mr0 = spr_perm(src_r0, m), mr1 = spr_perm(src_r1, m), mc0 = spr_perm(src_c0, m),
+                         mc1 = spr_perm(src_c1, m);
+            __builtin_amdgcn_sched_barrier(0);      // (the exchanges are under way while the pivots are inverted)
+            const double d0 = 1.0 / m00;
+            const double l10 = m10 * d0;
+            const double d1 = 1.0 / fma(-l10, m10, m11);
+            const double y1 = fma(-l10, mc0, mc1);
+            const double z0 = mc0 * d0, z1 = y1 * d1;
+            const double s0 = fma(-l10, z1, z0);
+            const double k0j = -s0, k1j = -z1;
+            const double e = fma(mr0, k0j, m);
+            pnew = fma(mr1, k1j, e);
+            {
+                ldouble *ob = stg + (k - klo) * SPR_REC;
+                const int back = (k - klo) * SPR_REC;
+                ob[(oA >= 0) ? oA : spare - back] = diag ? k0j : kvl ? m : l10;
+                ob[(oB >= 0) ? oB : spare - back] = diag ? k1j : d0;
+                if (lane == 0) ob[12] = d1;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { bc[i] = nbc[i]; br[i] = nbr[i]; }
+            ht = nht;
+            base = nb;
+        }
+        lds_order();
+        if (lane >= klo && lane <= khi) {
+            const ldouble *w = stg + (lane - klo) * SPR_REC;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { ro.K[0][i] = w[i]; ro.K[1][i] = w[5 + i]; }
+            ro.l10 = w[10]; ro.d0 = w[11]; ro.d1 = w[12]; ro.kv[0] = w[13]; ro.kv[1] = w[14];
+        }
+    }
+    lds_order();
+}
+
 template <int NH>
 __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, gopts *op, int sp_have_mode,
                                                      double sp_sigma_mu, double sp_alpha, int m_total, int qit_max,
@@ -2592,7 +2772,8 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, gopts *op, int
     const bool sp_have = ((sp_have_mode >> 8) & 1) != 0;
     const int sp_mode = sp_have_mode & 255;
     int qit = qit_max & 0xffff;
-    const int max_iters = qit_max >> 16;
+    const int max_iters = (qit_max >> 16) & 0x7fff;
+    const bool spread = NH == 0 && (qit_max < 0);      // (the sign bit: the kernel has the staging area and the caller wants it used)
     typedef Map<NH> M;
     COOP_UNPACK(NH);
     const mpcx_opts ol = opts_in_registers(op);
@@ -2678,6 +2859,9 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, gopts *op, int
             break;
         }
         // ================= Riccati factorisation and the affine backward substitution =================
+        if (spread) {
+            burst_ric_spread(t, S.hB, N, ret - j, ro, sum);
+        } else {
         if (kj == N) stage_B0_ric<LAST>(S, t, Po, po, Po, po, ro);
         // the factorisation down the lanes ...
         for (int s = 0; s < N; ++s) {
@@ -2707,6 +2891,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, gopts *op, int
                 if (kj < N) stage_B0_ric<MID, false, 2>(S, tp, nullptr, pi, nullptr, po, rp);
             }
             ro.kv[0] = rp.kv[0]; ro.kv[1] = rp.kv[1];
+        }
         }
         if (kj < N) feed_forward(ro.l10, ro.d0, ro.d1, ro.kv[0], ro.kv[1], ro.kv);
         const double mu = uniform(bcast(sum, 0) / (double)m_total);
@@ -3046,7 +3231,7 @@ template <int NH>
 __global__ void __launch_bounds__(64) __attribute__((disable_tail_calls))
 mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
                 int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots, unsigned deal, int burst_few,
-                double hold_alpha, int hold_extra, int boost_mul)
+                double hold_alpha, int hold_extra, int boost_mul, int dedicate_min, int spread_on)
 {
     const mpcx_opts &o = *op_generic;
     gopts *op = (gopts *)op_generic;      // what the sweeps are handed
@@ -3056,7 +3241,9 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
     // stage records of the [stage][field][lane] layout, then `slots` single-problem regions
     const size_t wave_doubles = (size_t)((N + 1) + slots * ((N + 64) / 64)) * M::F * 64;
 
-    __shared__ double pc_lds[(PCN<NH>::N + 6) * 64];      // constants, 5 result slots, carry words
+    // constants, 5 result slots, carry words; without obstacle rows there is room for the staging area of
+    // burst_ric_spread() beside them with four workgroups on a compute unit (40 KB each)
+    __shared__ double pc_lds[(PCN<NH>::N + 6) * 64 + ((NH == 0) ? SPR_EXTRA : 0)];
     PC<NH> pc;
     pc.p = (ldouble *)pc_lds + threadIdx.x;
     pc.lmk = 0.0;
@@ -3086,6 +3273,9 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
     sp.have = false; sp.mode = 0; sp.sigma_mu = 0.0; sp.alpha = 0.0;
 
     STAMP_DECL();
+#ifdef MPCX_STAMPS
+    unsigned long long t_fetch = 0;
+#endif
     if (threadIdx.x == 0) MARK(21);
     // what a lane decides after sweep L of its problem (not in real-time-iteration mode's second call)
     auto after_L = [&]() {
@@ -3239,7 +3429,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
         if (max_iters > 0x7fff) max_iters = 0x7fff;
         if (max_iters < 1) max_iters = 1;
         coop_burst<NH>(COOP_PASS(C, pcc), op, (have << 8) | (mode & 255), sgm, alp, mt,
-                       (max_iters << 16) | (qit0 & 0xffff), ret);
+                       (int)((spread_on ? 0x80000000u : 0u) | ((unsigned)max_iters << 16) | ((unsigned)qit0 & 0xffffu)), ret);
         ldouble *carry = ret - threadIdx.x + 5 * 64;
         const int n_state = (int)uniform(carry[BR_STATE]), n_status = (int)uniform(carry[BR_STATUS]),
                   add_total = (int)uniform(carry[BR_ADD_TOTAL]), add_sqp = (int)uniform(carry[BR_ADD_SQP]),
@@ -3323,7 +3513,14 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
             }
         }
         // ---- service: results out, next problem in, new SQP iteration ---------------------
-        const bool wants = (state == LS_OUT) || (state == LS_FETCH) || (state == LS_LIN);
+        // A wavefront that carries a very old problem takes no new ones until that problem has ended.  The
+        // longest problem of a batch ends the launch, and every problem its wavefront takes on costs it
+        // time: a tick of the one-lane-per-problem sweeps, and a burst of its own for each that grows old in
+        // turn.  The lanes that run empty wait; the problems they would have taken go to other wavefronts.
+        const bool hog = dedicate_min > 0 && !o.rti &&
+                         __any(((state == LS_QP) || (state == LS_LIN)) &&
+                               qp_total + ((state == LS_QP) ? qp_it : 0) >= dedicate_min);
+        const bool wants = (state == LS_OUT) || (state == LS_FETCH && !hog) || (state == LS_LIN);
         const int n_wants = __popcll(__ballot(wants));
         const int n_qp = __popcll(__ballot(state == LS_QP));
         const bool few = n_qp <= coop_max;     // single-problem mode ahead
@@ -3364,6 +3561,14 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
             }
             if (state == LS_OUT) {
                 const size_t b = L.b;
+#ifdef MPCX_STAMPS
+                if (qp_total >= 5000 && g_stamps[blockIdx.x][41] == 0) {      // the end of a very long problem, and when it was fetched
+                    g_stamps[blockIdx.x][41] = wall_clock64();
+                    g_stamps[blockIdx.x][43] = (unsigned long long)qp_total;
+                    g_stamps[blockIdx.x][45] = t_fetch;
+                    g_stamps[blockIdx.x][47] = (unsigned long long)b;
+                }
+#endif
                 L.roff = 0;
                 solo = false;
                 out.status[b] = status;
@@ -3376,7 +3581,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
             }
             STAMP(8, st_e);
             [[maybe_unused]] const bool st_a = (state == LS_FETCH);
-            if (state == LS_FETCH) {
+            if (state == LS_FETCH && !hog) {
                 // Fetch order.  The batch is taken in the caller's order in blocks of 65536 problems;
                 // inside a block the c-th fetch takes problem (c * g) mod (block size), g coprime to the
                 // size and near its golden-section point, so consecutive fetches lie far apart: problems
@@ -3395,6 +3600,9 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
                 } else {
                     L.b = b;
                     L.roff = 0;
+#ifdef MPCX_STAMPS
+                    t_fetch = wall_clock64();
+#endif
                     int nobs = in.n_obs ? in.n_obs[b] : 0;
                     // (the host validates it; stay memory safe)
                     if (nobs < 0 || nobs > NH) {
@@ -3638,6 +3846,9 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
                 if (k < 1) k = 1;
                 budget -= k;
                 if (threadIdx.x == 0 && best >= 1000) MARK(23);
+                if (threadIdx.x == 0) {
+                    MARK_AGE(12, 1000, best); MARK_AGE(14, 2000, best); MARK_AGE(36, 4000, best); MARK_AGE(38, 8000, best);
+                }
                 for (int t = 0; t < k;) {
                     const int st = __builtin_amdgcn_readlane(state, p);
                     if (st == LS_QP) {
@@ -3763,6 +3974,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
         double a = 0.0; int x = 0;
         if (sscanf(e, "%lf,%d", &a, &x) == 2 && a >= 0.0 && x >= 0) { hold_alpha = a; hold_extra = x; }
     }
+    // interior-point iterations after which a problem keeps its wavefront from taking new problems (0: never)
+    int dedicate_min = 512;
+    if (const char *e = getenv("MPCX_DEDICATE")) { int v = atoi(e); if (v >= 0) dedicate_min = v; }
+    // 1: the Riccati recursion of a burst with one stage's algebra spread over the lanes; 0: as lane pipelines
+    int spread_on = 1;
+    if (const char *e = getenv("MPCX_SPREAD")) spread_on = atoi(e) != 0;
     int svc_min = MPCX_SERVICE_MIN;
     if (const char *e = getenv("MPCX_SVC_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) svc_min = v; }
     if (coop_max < 0 || coop_max > 64) return hipErrorInvalidValue;
@@ -3793,12 +4010,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     }
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, dedicate_min, spread_on); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, dedicate_min, spread_on); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, dedicate_min, spread_on); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, dedicate_min, spread_on); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, dedicate_min, spread_on); break;
 #else
     default: return hipErrorInvalidValue;
 #endif

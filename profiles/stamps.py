@@ -26,6 +26,9 @@ if os.environ.get("STAMPS_GRID"):
     import cases
     from mpc_amd.batch import pack_problems
     packed = pack_problems(*cases.grid_problems())
+elif os.environ.get("STAMPS_REACHABLE"):
+    from mpc_amd.synthetic import reachable_batch
+    packed = reachable_batch(B)
 else:
     packed = synthetic_batch(B)
 if ONLY >= 0:
@@ -47,6 +50,13 @@ print(f"B={B} wall {dt:.2f}s (incl. transfers); waves with work: {used.sum()}")
 mark_slots = [20, 21, 22, 23]
 marks_raw = cyc[:, mark_slots].copy()
 cyc[:, mark_slots] = 0
+# (time, age) pairs: first burst of a problem at least 1000 / 2000 / 4000 / 8000 iterations old; the end of a
+# problem of 5000 iterations or more with the time of its fetch and its index
+age_marks = {thr: (buf[:, w].astype(np.float64), buf[:, w + 1].astype(np.int64))
+             for thr, w in ((1000, 12), (2000, 14), (4000, 36), (8000, 38))}
+long_end = (buf[:, 41].astype(np.float64), buf[:, 43].astype(np.int64), buf[:, 45].astype(np.float64), buf[:, 47].astype(np.int64))
+cyc[:, [6, 7, 18, 19]] = 0
+cnt[:, [20, 21, 22, 23]] = 0
 # parts of the single-problem sweeps (already contained in slots 12..15)
 # bursts (N < 64): slot 12 holds whole bursts, lanes-sum / 64 = iterations + QP ends
 sub_slots = {16: "    burst: B0 rows + reductions", 17: "    burst: Riccati pipeline", 24: "    burst: F affine", 25: "    burst: Bs", 26: "    burst: F both",
@@ -79,3 +89,12 @@ for name, col in (("start", 1), ("queue seen empty", 0), ("first extra iteration
         r = (v - t0) / 1e8
         print(f"mark {name:52s} waves {v.size:5d}  min {r.min():.3f}s median {np.median(r):.3f}s "
               f"p90 {np.percentile(r, 90):.3f}s max {r.max():.3f}s")
+
+# the life of every very long problem (5000 iterations or more), from its wavefront's marks
+for w in np.nonzero(long_end[0] > 0)[0]:
+    line = f"wave {w:4d}: problem {long_end[3][w]} fetched {(long_end[2][w] - t0) / 1e8:.3f}s"
+    for thr, (tm, ag) in age_marks.items():
+        if tm[w] > 0:
+            line += f", age {ag[w]} at {(tm[w] - t0) / 1e8:.3f}s"
+    line += f", ended with {long_end[1][w]} iterations at {(long_end[0][w] - t0) / 1e8:.3f}s"
+    print(line)
