@@ -2599,7 +2599,8 @@ static_assert(MPCX_STORE_RECIP == 0, "the resident burst keeps the slack recipro
 // The lane pipelines execute a stage's ~390 instructions in every lane for one useful lane a step.  Here the
 // stages are taken in turn, N down to 0, and lane 8 r + c, r < 7, owns entry (r, c) of
 // M = Ht + [B A]' P(k+1) [B A] for c < 7 and entry r of the right-hand side m = gt + [B A]' (p(k+1) + P(k+1) rb)
-// for c = 7: P(k+1) and p(k+1) travel as 20 wave-uniform values (v_readlane), every lane forms its column of
+// for c = 7: P(k+1) travels as 15 wave-uniform values (v_readlane), p(k+1) reaches the right-hand-side lanes by
+// ds_bpermute (the other lanes read -0 from lane 63 in the same instruction), every lane forms its column of
 // P(k+1) [B A] (the right-hand-side lanes: P(k+1) rb, then + p(k+1)) and its entry with five multiply-adds
 // each, every lane factorises the 2 x 2 input block itself, and one multiply-add pair gives entry (r, c) of
 // P(k) = M_xx + M_xu K in the entry lanes and entry r of p(k) = m_x + K' m_u in the right-hand-side lanes (the
@@ -2608,16 +2609,21 @@ static_assert(MPCX_STORE_RECIP == 0, "the resident burst keeps the slack recipro
 // by a structural 1 or an addition of a structural 0 product leaves a finite number as it is.
 //
 // The operands of a stage are uniform per step, so they come from LDS: the stage's own lane writes a record
-// of SPR_REC doubles ([0,14) the pattern entries of A and B; 14 hB; 15 zero; 16 one; [17,24) the diagonal of the
-// barrier Hessian, the (x, y) block's added; 24 its off-diagonal entry; [25,30) rb; [30,37) gt), SPR_CH stages at
-// a time, and takes the results back from it ([0,5) K row 0; [5,10) K row 1; 10 l10; 11, 12 the reciprocal
+// of SPR_REC doubles (word 37 takes the stores of lanes that have no result; [0,14) the pattern entries of A and B; 14 hB; 15 zero; 16 one; [17,24) the diagonal of the
+// barrier Hessian, the (x, y) block's added; 24 its off-diagonal entry; [25,30) rb; [30,37) gt), CH stages at
+// a time (CH), and takes the results back from it ([0,5) K row 0; [5,10) K row 1; 10 l10; 11, 12 the reciprocal
 // pivots; 13, 14 the input part of the right-hand side).  `stg` is the wavefront's staging area of
-// SPR_CH * SPR_REC + 1 doubles.  The complementarity sum rides along as before, one pipeline step per stage.
+// CH * SPR_REC doubles.  The complementarity sum rides along as before, one pipeline step per stage.
 // ---------------------------------------------------------------------------
-#define SPR_REC 37
-#define SPR_CH 25
-#define SPR_EXTRA 704      // doubles of LDS per wavefront beyond the result slots and carry words, which the staging area also covers
-static_assert(SPR_CH * SPR_REC + 1 <= 6 * 64 + SPR_EXTRA, "staging area");
+#define SPR_REC 38
+// Doubles of LDS per wavefront beyond the result slots and carry words (which the staging area also covers), and the
+// stages staged at a time: what is left of 40 KB -- four workgroups on a compute unit -- beside the problem
+// constants, which grow with the obstacle rows; with four obstacles three workgroups fit anyway.
+template <int NH> struct Spr {
+    static constexpr int EXTRA = (NH == 0 || NH == 4) ? 704 : 5120 - (PCN<NH>::N + 6) * 64;
+    static constexpr int CH = ((6 * 64 + EXTRA) / SPR_REC > 25) ? 25 : (6 * 64 + EXTRA) / SPR_REC;
+    static_assert(EXTRA >= 0 && CH >= 8, "staging area");
+};
 
 DEV int spr_word(int c, int j)      // word of entry (j, c) of [B A | rb] in a staging record
 {
@@ -2640,6 +2646,7 @@ DEV double spr_perm(int addr, double v)
 }
 typedef __attribute__((address_space(3))) char lchar;
 
+template <int CH>
 DEV void burst_ric_spread(const B0Out &t, double hB, int N, ldouble *stg, RicOut &ro, double &sum)
 {
     const int lane = (int)threadIdx.x;
@@ -2652,19 +2659,22 @@ DEV void burst_ric_spread(const B0Out &t, double hB, int N, ldouble *stg, RicOut
     for (int j = 0; j < NX; ++j) { oc[j] = 8u * (unsigned)spr_word(cc, j); orr[j] = 8u * (unsigned)spr_word(rr, j); }
     const unsigned off_h = (cc == 7) ? 8u * (unsigned)(30 + rr)
                                      : 8u * (unsigned)((rr == cc) ? 17 + rr : (rr == 3 && cc == 2) ? 24 : 15);
-    // where a lane's results of a step go in the record: the diagonal lanes (NU+j, NU+j) have column j of K,
-    // lane 0 the pivots, the lanes (0, 7), (1, 7) the input part of the right-hand side; the rest a spare word
+    // where a lane's two results of a step go in the record: the diagonal lanes (NU+j, NU+j) have column j of K,
+    // lanes 0 and 1 the pivots, the lanes (0, 7), (1, 7) the input part of the right-hand side; the rest word 37
     const bool diag = ent && cc < 7 && rr == cc && rr >= NU;
     const bool kvl = rhs && rr < NU;
-    const int spare = SPR_CH * SPR_REC;
-    const int oA = diag ? (cc - NU) : (lane == 0) ? 10 : kvl ? 13 + rr : -1;
-    const int oB = diag ? (5 + cc - NU) : (lane == 0) ? 11 : -1;
+    const unsigned oA = 8u * (unsigned)(diag ? (cc - NU) : (lane == 0) ? 10 : kvl ? 13 + rr : 37);
+    const unsigned oB = 8u * (unsigned)(diag ? (5 + cc - NU) : (lane == 0) ? 11 : (lane == 1) ? 12 : 37);
     // exchange partners.  Entry lanes: M[r][0], M[r][1] of the row and M[c][0], M[c][1] of the column.
     // Right-hand-side lanes: m[0], m[1], and M[r][0], M[r][1] of the row
     const int src_r0 = 4 * (rhs ? 8 * 0 + 7 : 8 * rr + 0), src_r1 = 4 * (rhs ? 8 * 1 + 7 : 8 * rr + 1);
     const int src_c0 = 4 * (rhs ? 8 * rr + 0 : 8 * cc + 0), src_c1 = 4 * (rhs ? 8 * rr + 1 : 8 * cc + 1);
+    // p(k+1)[i] comes from its lane for the right-hand-side lanes and from lane 63, which holds -0, for the others
+    int src_p[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) src_p[i] = 4 * (rhs ? 8 * (NU + i) + 7 : 63);
     // P(N), p(N): the barrier Hessian and the gradient of the last stage, from its lane
-    double pnew = 0.0;
+    double pnew = (lane == 63) ? -0.0 : 0.0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
 #pragma unroll
@@ -2678,8 +2688,8 @@ DEV void burst_ric_spread(const B0Out &t, double hB, int N, ldouble *stg, RicOut
         const double g = bcast(t.gt[NU + i], N);
         pnew = (rr == NU + i && cc == 7) ? g : pnew;
     }
-    for (int khi = N - 1; khi >= 0; khi -= SPR_CH) {
-        const int klo = (khi - SPR_CH + 1 > 0) ? khi - SPR_CH + 1 : 0;
+    for (int khi = N - 1; khi >= 0; khi -= CH) {
+        const int klo = (khi - CH + 1 > 0) ? khi - CH + 1 : 0;
         lds_order();
         if (lane >= klo && lane <= khi) {
             ldouble *w = stg + (lane - klo) * SPR_REC;
@@ -2696,33 +2706,35 @@ DEV void burst_ric_spread(const B0Out &t, double hB, int N, ldouble *stg, RicOut
             for (int q = 0; q < NZ; ++q) w[30 + q] = t.gt[q];
         }
         lds_order();
-        const lchar *base = (const lchar *)stg + (khi - klo) * SPR_REC * 8;
+        lchar *base = (lchar *)stg + (khi - klo) * SPR_REC * 8;
         double bc[NX], br[NX], ht;
 #pragma unroll
         for (int i = 0; i < NX; ++i) { bc[i] = *(const ldouble *)(base + oc[i]); br[i] = *(const ldouble *)(base + orr[i]); }
         ht = *(const ldouble *)(base + off_h);
         for (int k = khi; k >= klo; --k) {
-            // the operands of the next stage are fetched while this one computes
+            // the operands of the next stage are fetched while this one computes (reading them at the top of
+            // their own step instead, behind the broadcast of P, measured 2 % of an iteration slower)
             double nbc[NX], nbr[NX], nht;
             const lchar *nb = (k > klo) ? base - SPR_REC * 8 : base;
 #pragma unroll
             for (int i = 0; i < NX; ++i) { nbc[i] = *(const ldouble *)(nb + oc[i]); nbr[i] = *(const ldouble *)(nb + orr[i]); }
             nht = *(const ldouble *)(nb + off_h);
             sum = lane_above<true>(sum, 0.0) + t.ssum;
-            double P[15], pn[NX];
+            double pn[NX];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) {
+            for (int i = 0; i < NX; ++i) pn[i] = spr_perm(src_p[i], pnew);
+            double P[15];
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
 #pragma unroll
                 for (int j = 0; j <= i; ++j) P[tri(i, j)] = bcast(pnew, 8 * (NU + i) + (NU + j));
-                pn[i] = bcast(pnew, 8 * (NU + i) + 7);
-            }
             double pba[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 double acc = psym(P, i, 0) * bc[0];
 #pragma unroll
                 for (int j = 1; j < NX; ++j) acc = fma(psym(P, i, j), bc[j], acc);
-                pba[i] = (rhs ? pn[i] : -0.0) + acc;      // (adding -0 changes no number)
+                pba[i] = pn[i] + acc;      // (adding -0 changes no number)
             }
             double m = ht;
 #pragma unroll
@@ -2739,18 +2751,14 @@ DEV void burst_ric_spread(const B0Out &t, double hB, int N, ldouble *stg, RicOut
             const double s0 = fma(-l10, z1, z0);
             const double k0j = -s0, k1j = -z1;
             const double e = fma(mr0, k0j, m);
-            pnew = fma(mr1, k1j, e);
-            {
-                ldouble *ob = stg + (k - klo) * SPR_REC;
-                const int back = (k - klo) * SPR_REC;
-                ob[(oA >= 0) ? oA : spare - back] = diag ? k0j : kvl ? m : l10;
-                ob[(oB >= 0) ? oB : spare - back] = diag ? k1j : d0;
-                if (lane == 0) ob[12] = d1;
-            }
+            const double pk = fma(mr1, k1j, e);
+            pnew = (lane == 63) ? -0.0 : pk;
+            *(ldouble *)(base + oA) = diag ? k0j : kvl ? m : l10;
+            *(ldouble *)(base + oB) = diag ? k1j : (lane == 1) ? d1 : d0;
 #pragma unroll
             for (int i = 0; i < NX; ++i) { bc[i] = nbc[i]; br[i] = nbr[i]; }
             ht = nht;
-            base = nb;
+            base -= SPR_REC * 8;
         }
         lds_order();
         if (lane >= klo && lane <= khi) {
@@ -2772,8 +2780,8 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, gopts *op, int
     const bool sp_have = ((sp_have_mode >> 8) & 1) != 0;
     const int sp_mode = sp_have_mode & 255;
     int qit = qit_max & 0xffff;
-    const int max_iters = (qit_max >> 16) & 0x7fff;
-    const bool spread = NH == 0 && (qit_max < 0);      // (the sign bit: the kernel has the staging area and the caller wants it used)
+    const int max_iters = (qit_max >> 16) & 0x3fff;
+    const bool spread = ((qit_max >> 30) & 1) != 0;      // (the sign bit: the kernel has the staging area and the caller wants it used)
     typedef Map<NH> M;
     COOP_UNPACK(NH);
     const mpcx_opts ol = opts_in_registers(op);
@@ -2860,7 +2868,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, gopts *op, int
         }
         // ================= Riccati factorisation and the affine backward substitution =================
         if (spread) {
-            burst_ric_spread(t, S.hB, N, ret - j, ro, sum);
+            burst_ric_spread<Spr<NH>::CH>(t, S.hB, N, ret - j, ro, sum);
         } else {
         if (kj == N) stage_B0_ric<LAST>(S, t, Po, po, Po, po, ro);
         // the factorisation down the lanes ...
@@ -3241,9 +3249,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
     // stage records of the [stage][field][lane] layout, then `slots` single-problem regions
     const size_t wave_doubles = (size_t)((N + 1) + slots * ((N + 64) / 64)) * M::F * 64;
 
-    // constants, 5 result slots, carry words; without obstacle rows there is room for the staging area of
-    // burst_ric_spread() beside them with four workgroups on a compute unit (40 KB each)
-    __shared__ double pc_lds[(PCN<NH>::N + 6) * 64 + ((NH == 0) ? SPR_EXTRA : 0)];
+    // constants, 5 result slots, carry words, and the rest of the staging area of burst_ric_spread()
+    __shared__ double pc_lds[(PCN<NH>::N + 6) * 64 + Spr<NH>::EXTRA];
     PC<NH> pc;
     pc.p = (ldouble *)pc_lds + threadIdx.x;
     pc.lmk = 0.0;
@@ -3426,10 +3433,10 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
         const double sgm = bcast(sp.sigma_mu, p), alp = bcast(sp.alpha, p);
         const int mt = __builtin_amdgcn_readlane(m_total, p);
         const int qit0 = __builtin_amdgcn_readlane(qp_it, p);
-        if (max_iters > 0x7fff) max_iters = 0x7fff;
+        if (max_iters > 0x3fff) max_iters = 0x3fff;
         if (max_iters < 1) max_iters = 1;
         coop_burst<NH>(COOP_PASS(C, pcc), op, (have << 8) | (mode & 255), sgm, alp, mt,
-                       (int)((spread_on ? 0x80000000u : 0u) | ((unsigned)max_iters << 16) | ((unsigned)qit0 & 0xffffu)), ret);
+                       (int)(((unsigned)spread_on << 30) | ((unsigned)max_iters << 16) | ((unsigned)qit0 & 0xffffu)), ret);
         ldouble *carry = ret - threadIdx.x + 5 * 64;
         const int n_state = (int)uniform(carry[BR_STATE]), n_status = (int)uniform(carry[BR_STATUS]),
                   add_total = (int)uniform(carry[BR_ADD_TOTAL]), add_sqp = (int)uniform(carry[BR_ADD_SQP]),

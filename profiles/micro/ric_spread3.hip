@@ -540,6 +540,164 @@ __global__ void __launch_bounds__(64) k_spread4(const StageIn *stages, double hB
     if (lane == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// SPREAD5 = SPREAD4 with fewer instructions a step (inside the solver the loop is bound by instruction issue):
+// no double buffer for the operands (they are read at the top of the step; the broadcast of P covers the LDS
+// latency); p(k+1) reaches the right-hand-side lanes by ds_bpermute, the other lanes read -0 from lane 63;
+// every lane has a fixed word of the record for each of its two result stores (word 37 for nothing); lane 1
+// writes the second pivot.  VAR bit 0: P(k+1) is broadcast through LDS (one write, ten 16-byte reads) instead of
+// 30 v_readlane.
+// ---------------------------------------------------------------------------------------------------
+#define REC5 38
+typedef double __attribute__((ext_vector_type(2))) dbl2;
+
+template <int CH, int VAR>
+__global__ void __launch_bounds__(64) k_spread5(const StageIn *stages, double hB, int N, int reps, StageOut *out, double *P0,
+                                                long long *cycles)
+{
+    __shared__ double rec[CH * REC5];
+    __shared__ __attribute__((aligned(16))) double pbc[16];
+    const int lane = (int)threadIdx.x;
+    const int r = lane >> 3, c = lane & 7;
+    const bool ent = r < NZ;
+    const bool rhs = ent && c == 7;
+    const int rr = ent ? r : 0, cc = ent ? c : 0;
+    const StageIn in = stages[(size_t)blockIdx.x * 64 + lane];
+    StageOut ro = {};
+    unsigned oc[NX], orr[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { oc[j] = 8u * (unsigned)ba_word(cc, j); orr[j] = 8u * (unsigned)ba_word(rr, j); }
+    const unsigned off_h = (cc == 7) ? 8u * (unsigned)(30 + rr)
+                                     : 8u * (unsigned)((rr == cc) ? 17 + rr : (rr == 3 && cc == 2) ? 24 : 15);
+    const bool diag = ent && cc < 7 && rr == cc && rr >= NU;
+    const bool kvl = rhs && rr < NU;
+    const unsigned oA = 8u * (unsigned)(diag ? (cc - NU) : (lane == 0) ? 10 : kvl ? 13 + rr : 37);
+    const unsigned oB = 8u * (unsigned)(diag ? (5 + cc - NU) : (lane == 0) ? 11 : (lane == 1) ? 12 : 37);
+    const int src_r0 = 4 * (rhs ? 8 * 0 + 7 : 8 * rr + 0), src_r1 = 4 * (rhs ? 8 * 1 + 7 : 8 * rr + 1);
+    const int src_c0 = 4 * (rhs ? 8 * rr + 0 : 8 * cc + 0), src_c1 = 4 * (rhs ? 8 * rr + 1 : 8 * cc + 1);
+    int src_p[NX];      // where p(k+1)[i] comes from: its lane for the right-hand-side lanes, lane 63 (-0) for the others
+#pragma unroll
+    for (int i = 0; i < NX; ++i) src_p[i] = 4 * (rhs ? 8 * (NU + i) + 7 : 63);
+    int pslot = -1;
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+            if (lane == 8 * (NU + i) + (NU + j)) pslot = tri(i, j);
+    double pnew = 0.0;
+    long long t0 = __builtin_amdgcn_s_memtime();
+    for (int rep = 0; rep < reps; ++rep) {
+        {
+            double e = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    const double v = rdlane(ht_entry(in, i, j), N);
+                    e = (rr == NU + i && cc == NU + j) ? v : e;
+                }
+                const double g = rdlane(in.gt[NU + i], N);
+                e = (rr == NU + i && cc == 7) ? g : e;
+            }
+            pnew = (lane == 63) ? -0.0 : e;
+        }
+        for (int khi = N - 1; khi >= 0; khi -= CH) {
+            const int klo = (khi - CH + 1 > 0) ? khi - CH + 1 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= klo && lane <= khi) {
+                double *w = rec + (lane - klo) * REC5;
+#pragma unroll
+                for (int q = 0; q < 14; ++q) w[q] = in.ab[q];
+                w[14] = hB; w[15] = 0.0; w[16] = 1.0;
+#pragma unroll
+                for (int q = 0; q < NZ; ++q) w[17 + q] = (q == 2) ? in.Ht[2] + in.hxx : (q == 3) ? in.Ht[3] + in.hyy : in.Ht[q];
+                w[24] = in.hxy;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) w[25 + i] = in.rb[i];
+#pragma unroll
+                for (int q = 0; q < NZ; ++q) w[30 + q] = in.gt[q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const char *base = (const char *)rec + (size_t)(khi - klo) * REC5 * 8;
+            for (int k = khi; k >= klo; --k) {
+                if (VAR & 1) {
+                    if (pslot >= 0) pbc[pslot] = pnew;
+                }
+                double bc[NX], br[NX], ht;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { bc[i] = *(const double *)(base + oc[i]); br[i] = *(const double *)(base + orr[i]); }
+                ht = *(const double *)(base + off_h);
+                double pn[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) pn[i] = bperm(src_p[i], pnew);
+                double P[16];
+                if (VAR & 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const dbl2 v = *(const dbl2 *)&pbc[2 * i];
+                        P[2 * i] = v.x; P[2 * i + 1] = v.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i)
+#pragma unroll
+                        for (int j = 0; j <= i; ++j) P[tri(i, j)] = rdlane(pnew, 8 * (NU + i) + (NU + j));
+                }
+                double pba[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    double acc = psym(P, i, 0) * bc[0];
+#pragma unroll
+                    for (int j = 1; j < NX; ++j) acc = fma(psym(P, i, j), bc[j], acc);
+                    pba[i] = pn[i] + acc;
+                }
+                double m = ht;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) m = fma(br[i], pba[i], m);
+                const double m00 = rdlane(m, 0), m10 = rdlane(m, 8), m11 = rdlane(m, 9);
+                const double mr0 = bperm(src_r0, m), mr1 = bperm(src_r1, m), mc0 = bperm(src_c0, m), mc1 = bperm(src_c1, m);
+                __builtin_amdgcn_sched_barrier(0);
+                const double d0 = 1.0 / m00;
+                const double l10 = m10 * d0;
+                const double d1 = 1.0 / fma(-l10, m10, m11);
+                const double y1 = fma(-l10, mc0, mc1);
+                const double z0 = mc0 * d0, z1 = y1 * d1;
+                const double s0 = fma(-l10, z1, z0);
+                const double k0j = -s0, k1j = -z1;
+                const double e = fma(mr0, k0j, m);
+                const double pk = fma(mr1, k1j, e);
+                pnew = (lane == 63) ? -0.0 : pk;
+                *(double *)((char *)base + oA) = diag ? k0j : kvl ? m : l10;
+                *(double *)((char *)base + oB) = diag ? k1j : (lane == 1) ? d1 : d0;
+                base -= REC5 * 8;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= klo && lane <= khi) {
+                const double *w = rec + (lane - klo) * REC5;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { ro.K[0][i] = w[i]; ro.K[1][i] = w[5 + i]; }
+                ro.l10 = w[10]; ro.d0 = w[11]; ro.d1 = w[12]; ro.kv[0] = w[13]; ro.kv[1] = w[14];
+            }
+        }
+        pnew = fresh(pnew);
+    }
+    long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane <= N) out[(size_t)blockIdx.x * 64 + lane] = ro;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+            if (lane == 8 * (NU + i) + (NU + j)) P0[(size_t)blockIdx.x * 20 + tri(i, j)] = pnew;
+        if (lane == 8 * (NU + i) + 7) P0[(size_t)blockIdx.x * 20 + 15 + i] = pnew;
+    }
+    if (lane == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 static double urand(unsigned long long &s)
 {
     s = s * 6364136223846793005ull + 1442695040888963407ull;
@@ -627,8 +785,19 @@ int main(int argc, char **argv)
         if (pass) { report("SPREAD4, " #CH_ " staged", ms); ok = check("SPREAD4, " #CH_ " staged") && ok; } \
     }
     RUN_SPREAD4(64)
-    RUN_SPREAD4(17)
     RUN_SPREAD4(25)
+#define RUN_SPREAD5(CH_, VAR_)                                                                               \
+    for (int pass = 0; pass < 2; ++pass) {                                                                   \
+        hipMemset(d_o2, 0, st.size() * sizeof(StageOut));                                                    \
+        hipEventRecord(e0);                                                                                  \
+        hipLaunchKernelGGL((k_spread5<CH_, VAR_>), dim3(WG), dim3(64), 0, 0, d_st, hB, N, reps, d_o2, d_p2, d_cy); \
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);                       \
+        if (pass) { report("SPREAD5 var " #VAR_ ", " #CH_ " staged", ms); ok = check("SPREAD5 var " #VAR_ ", " #CH_ " staged") && ok; } \
+    }
+    RUN_SPREAD5(64, 0)
+    RUN_SPREAD5(25, 0)
+    RUN_SPREAD5(64, 1)
+    RUN_SPREAD5(25, 1)
     if (hipDeviceSynchronize() != hipSuccess) { printf("HIP error\n"); return 2; }
     return ok ? 0 : 1;
 }
