@@ -3239,7 +3239,7 @@ template <int NH>
 __global__ void __launch_bounds__(64) __attribute__((disable_tail_calls))
 mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
                 int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots, unsigned deal, int burst_few,
-                double hold_alpha, int hold_extra, int boost_mul, int dedicate_min, int spread_on)
+                double hold_alpha, int hold_extra, int boost_mul, int spread_on)
 {
     const mpcx_opts &o = *op_generic;
     gopts *op = (gopts *)op_generic;      // what the sweeps are handed
@@ -3520,14 +3520,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
             }
         }
         // ---- service: results out, next problem in, new SQP iteration ---------------------
-        // A wavefront that carries a very old problem takes no new ones until that problem has ended.  The
-        // longest problem of a batch ends the launch, and every problem its wavefront takes on costs it
-        // time: a tick of the one-lane-per-problem sweeps, and a burst of its own for each that grows old in
-        // turn.  The lanes that run empty wait; the problems they would have taken go to other wavefronts.
-        const bool hog = dedicate_min > 0 && !o.rti &&
-                         __any(((state == LS_QP) || (state == LS_LIN)) &&
-                               qp_total + ((state == LS_QP) ? qp_it : 0) >= dedicate_min);
-        const bool wants = (state == LS_OUT) || (state == LS_FETCH && !hog) || (state == LS_LIN);
+        const bool wants = (state == LS_OUT) || (state == LS_FETCH) || (state == LS_LIN);
         const int n_wants = __popcll(__ballot(wants));
         const int n_qp = __popcll(__ballot(state == LS_QP));
         const bool few = n_qp <= coop_max;     // single-problem mode ahead
@@ -3575,6 +3568,10 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
                     g_stamps[blockIdx.x][45] = t_fetch;
                     g_stamps[blockIdx.x][47] = (unsigned long long)b;
                 }
+                // the last problem the wavefront writes out: when, how long, fetched when
+                g_stamps[blockIdx.x][49] = wall_clock64();
+                g_stamps[blockIdx.x][51] = (unsigned long long)qp_total;
+                g_stamps[blockIdx.x][53] = t_fetch;
 #endif
                 L.roff = 0;
                 solo = false;
@@ -3588,7 +3585,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
             }
             STAMP(8, st_e);
             [[maybe_unused]] const bool st_a = (state == LS_FETCH);
-            if (state == LS_FETCH && !hog) {
+            if (state == LS_FETCH) {
                 // Fetch order.  The batch is taken in the caller's order in blocks of 65536 problems;
                 // inside a block the c-th fetch takes problem (c * g) mod (block size), g coprime to the
                 // size and near its golden-section point, so consecutive fetches lie far apart: problems
@@ -3981,9 +3978,6 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
         double a = 0.0; int x = 0;
         if (sscanf(e, "%lf,%d", &a, &x) == 2 && a >= 0.0 && x >= 0) { hold_alpha = a; hold_extra = x; }
     }
-    // interior-point iterations after which a problem keeps its wavefront from taking new problems (0: never)
-    int dedicate_min = 512;
-    if (const char *e = getenv("MPCX_DEDICATE")) { int v = atoi(e); if (v >= 0) dedicate_min = v; }
     // 1: the Riccati recursion of a burst with one stage's algebra spread over the lanes; 0: as lane pipelines
     int spread_on = 1;
     if (const char *e = getenv("MPCX_SPREAD")) spread_on = atoi(e) != 0;
@@ -4017,12 +4011,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     }
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, dedicate_min, spread_on); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, dedicate_min, spread_on); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, dedicate_min, spread_on); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, dedicate_min, spread_on); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, dedicate_min, spread_on); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on); break;
 #else
     default: return hipErrorInvalidValue;
 #endif

@@ -57,6 +57,8 @@ age_marks = {thr: (buf[:, w].astype(np.float64), buf[:, w + 1].astype(np.int64))
 long_end = (buf[:, 41].astype(np.float64), buf[:, 43].astype(np.int64), buf[:, 45].astype(np.float64), buf[:, 47].astype(np.int64))
 cyc[:, [6, 7, 18, 19]] = 0
 cnt[:, [20, 21, 22, 23]] = 0
+last_out = (buf[:, 49].astype(np.float64), buf[:, 51].astype(np.int64), buf[:, 53].astype(np.float64))
+cnt[:, [24, 25, 26]] = 0
 # parts of the single-problem sweeps (already contained in slots 12..15)
 # bursts (N < 64): slot 12 holds whole bursts, lanes-sum / 64 = iterations + QP ends
 sub_slots = {16: "    burst: B0 rows + reductions", 17: "    burst: Riccati pipeline", 24: "    burst: F affine", 25: "    burst: Bs", 26: "    burst: F both",
@@ -98,3 +100,10 @@ for w in np.nonzero(long_end[0] > 0)[0]:
             line += f", age {ag[w]} at {(tm[w] - t0) / 1e8:.3f}s"
     line += f", ended with {long_end[1][w]} iterations at {(long_end[0][w] - t0) / 1e8:.3f}s"
     print(line)
+
+# the wavefronts that leave last: the last problem each wrote out
+ex = marks_raw[:, 2].copy()
+ex[~used] = 0
+for w in np.argsort(-ex)[:12]:
+    print(f"wave {w:4d} exit {(ex[w] - t0) / 1e8:.3f}s: last problem out at {(last_out[0][w] - t0) / 1e8:.3f}s, "
+          f"{last_out[1][w]} iterations, fetched {(last_out[2][w] - t0) / 1e8:.3f}s")
