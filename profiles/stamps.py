@@ -56,6 +56,7 @@ age_marks = {thr: (buf[:, w].astype(np.float64), buf[:, w + 1].astype(np.int64))
              for thr, w in ((1000, 12), (2000, 14), (4000, 36), (8000, 38))}
 long_end = (buf[:, 41].astype(np.float64), buf[:, 43].astype(np.int64), buf[:, 45].astype(np.float64), buf[:, 47].astype(np.int64))
 cyc[:, [6, 7, 18, 19]] = 0
+cnt[:, [6, 7, 18, 19]] = 0
 cnt[:, [20, 21, 22, 23]] = 0
 last_out = (buf[:, 49].astype(np.float64), buf[:, 51].astype(np.int64), buf[:, 53].astype(np.float64))
 cnt[:, [24, 25, 26]] = 0
