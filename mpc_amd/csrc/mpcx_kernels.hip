@@ -2106,11 +2106,11 @@ __device__ unsigned long long g_stamps[2048][N_STAMP];
     } while (0)
 #define MARK_LAST(slot) do { g_stamps[blockIdx.x][2 * (slot)] = wall_clock64(); } while (0)
 // time and age when the wavefront first starts a burst of a problem at least `thr` iterations old (two words)
-#define MARK_AGE(word, thr, age)                                                           \
+#define MARK_AGE(word, word_age, thr, age)                                                 \
     do {                                                                                   \
         if ((age) >= (thr) && g_stamps[blockIdx.x][word] == 0) {                           \
             g_stamps[blockIdx.x][word] = wall_clock64();                                   \
-            g_stamps[blockIdx.x][(word) + 1] = (unsigned long long)(age);                  \
+            g_stamps[blockIdx.x][word_age] = (unsigned long long)(age);                    \
         }                                                                                  \
     } while (0)
 // cycles of a part of a non-inlined function (slots 16..19)
@@ -2124,7 +2124,7 @@ __device__ unsigned long long g_stamps[2048][N_STAMP];
 #else
 #define MARK(slot) ((void)0)
 #define MARK_LAST(slot) ((void)0)
-#define MARK_AGE(word, thr, age) ((void)0)
+#define MARK_AGE(word, word_age, thr, age) ((void)0)
 #define STAMP_DECL() ((void)0)
 #define STAMP_BEGIN() ((void)0)
 #define STAMP(slot, pred) ((void)0)
@@ -2311,20 +2311,220 @@ DEV void lds_order()
     __builtin_amdgcn_wave_barrier();
 }
 
+#define SPR_REC 38
+// Doubles of LDS per wavefront between the result slots and the carry words, and the stages staged at a time:
+// what is left of 40 KB -- four workgroups on a compute unit -- beside the problem constants, which grow with the
+// obstacle rows; with four obstacles three workgroups fit anyway.  The staging area starts at the result slots
+// (free while a recursion runs); a burst, which needs the carry words only when it ends, lets it run over them.
+template <int NH> struct Spr {
+    static constexpr int EXTRA = (NH == 0 || NH == 4) ? 704 : 5120 - (PCN<NH>::N + 6) * 64;
+    static constexpr int CH_BURST = ((6 * 64 + EXTRA) / SPR_REC > 25) ? 25 : (6 * 64 + EXTRA) / SPR_REC;
+    static constexpr int CH_BLOCK = ((5 * 64 + EXTRA) / SPR_REC > 25) ? 25 : (5 * 64 + EXTRA) / SPR_REC;
+    static constexpr int CARRY = 5 * 64 + EXTRA;      // the carry words, in doubles behind the first result slot
+    static_assert(EXTRA >= 0 && CH_BURST >= 8 && CH_BLOCK >= 8, "staging area");
+};
+
+// ---------------------------------------------------------------------------
+// The backward Riccati recursion of a block of stages held one per lane (a burst's whole horizon, or one of
+// the 64-stage blocks of a long one) -- factors and the affine backward substitution -- with the algebra of
+// ONE stage spread over the lanes instead of a lane pipeline over the stages.
+//
+// The lane pipelines execute a stage's ~390 instructions in every lane for one useful lane a step.  Here the
+// stages are taken in turn, N down to 0, and lane 8 r + c, r < 7, owns entry (r, c) of
+// M = Ht + [B A]' P(k+1) [B A] for c < 7 and entry r of the right-hand side m = gt + [B A]' (p(k+1) + P(k+1) rb)
+// for c = 7: P(k+1) travels as 15 wave-uniform values (v_readlane), p(k+1) reaches the right-hand-side lanes by
+// ds_bpermute (the other lanes read -0 from lane 63 in the same instruction), every lane forms its column of
+// P(k+1) [B A] (the right-hand-side lanes: P(k+1) rb, then + p(k+1)) and its entry with five multiply-adds
+// each, every lane factorises the 2 x 2 input block itself, and one multiply-add pair gives entry (r, c) of
+// P(k) = M_xx + M_xu K in the entry lanes and entry r of p(k) = m_x + K' m_u in the right-hand-side lanes (the
+// same two instructions on other exchange partners).  Every number is produced by the operations of
+// stage_B0_ric() in their order: the dense chains here contain the pattern chains there, and a multiplication
+// by a structural 1 or an addition of a structural 0 product leaves a finite number as it is.
+//
+// The operands of a stage are uniform per step, so they come from LDS: the stage's own lane writes a record
+// of SPR_REC doubles (word 37 takes the stores of lanes that have no result; [0,14) the pattern entries of A and B; 14 hB; 15 zero; 16 one; [17,24) the diagonal of the
+// barrier Hessian, the (x, y) block's added; 24 its off-diagonal entry; [25,30) rb; [30,37) gt), CH stages at
+// a time (CH), and takes the results back from it ([0,5) K row 0; [5,10) K row 1; 10 l10; 11, 12 the reciprocal
+// pivots; 13, 14 the input part of the right-hand side).  `stg` is the wavefront's staging area of
+// CH * SPR_REC doubles.  The lanes 0 .. nst-1 hold the stages to be done, the highest first.  P and p of the
+// stage above them come from lane `jinit` if that lane holds the last stage of the horizon (its barrier Hessian
+// and gradient), else (jinit < 0) from cP, cp, what the block above left; on return `pnew` holds P and p of the
+// block's lowest stage, entry (i, j) of P in lane 8 (NU+i) + NU+j, entry i of p in lane 8 (NU+i) + 7.
+// SUM: the complementarity sum rides along, one pipeline step per stage.
+// ---------------------------------------------------------------------------
+DEV int spr_word(int c, int j)      // word of entry (j, c) of [B A | rb] in a staging record
+{
+    switch (c) {
+    case 0: return (j == 0) ? 8 : (j == 1) ? 9 : (j == 2) ? 10 : (j == 3) ? 14 : 15;
+    case 1: return (j == 0) ? 11 : (j == 1) ? 12 : (j == 2) ? 13 : (j == 3) ? 15 : 14;
+    case 2: return (j == 0) ? 16 : 15;
+    case 3: return (j == 1) ? 16 : 15;
+    case 4: return (j == 0) ? 0 : (j == 1) ? 3 : (j == 2) ? 16 : 15;
+    case 5: return (j == 0) ? 1 : (j == 1) ? 4 : (j == 2) ? 6 : (j == 3) ? 16 : 15;
+    case 6: return (j == 0) ? 2 : (j == 1) ? 5 : (j == 2) ? 7 : (j == 3) ? 15 : 16;
+    default: return 25 + j;
+    }
+}
+DEV double spr_perm(int addr, double v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+typedef __attribute__((address_space(3))) char lchar;
+
+template <int CH, bool SUM>
+DEV void ric_spread(const B0Out &t, double hB, int nst, int jinit, const double *cP, const double *cp, ldouble *stg,
+                    RicOut &ro, double &sum, double &pnew)
+{
+    const int lane = (int)threadIdx.x;
+    const int r = lane >> 3, c = lane & 7;
+    const bool ent = r < NZ;
+    const bool rhs = ent && c == 7;
+    const int rr = ent ? r : 0, cc = ent ? c : 0;      // (lanes without an entry run along on entry (0, 0))
+    unsigned oc[NX], orr[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { oc[j] = 8u * (unsigned)spr_word(cc, j); orr[j] = 8u * (unsigned)spr_word(rr, j); }
+    const unsigned off_h = (cc == 7) ? 8u * (unsigned)(30 + rr)
+                                     : 8u * (unsigned)((rr == cc) ? 17 + rr : (rr == 3 && cc == 2) ? 24 : 15);
+    // where a lane's two results of a step go in the record: the diagonal lanes (NU+j, NU+j) have column j of K,
+    // lanes 0 and 1 the pivots, the lanes (0, 7), (1, 7) the input part of the right-hand side; the rest word 37
+    const bool diag = ent && cc < 7 && rr == cc && rr >= NU;
+    const bool kvl = rhs && rr < NU;
+    const unsigned oA = 8u * (unsigned)(diag ? (cc - NU) : (lane == 0) ? 10 : kvl ? 13 + rr : 37);
+    const unsigned oB = 8u * (unsigned)(diag ? (5 + cc - NU) : (lane == 0) ? 11 : (lane == 1) ? 12 : 37);
+    // exchange partners.  Entry lanes: M[r][0], M[r][1] of the row and M[c][0], M[c][1] of the column.
+    // Right-hand-side lanes: m[0], m[1], and M[r][0], M[r][1] of the row
+    const int src_r0 = 4 * (rhs ? 8 * 0 + 7 : 8 * rr + 0), src_r1 = 4 * (rhs ? 8 * 1 + 7 : 8 * rr + 1);
+    const int src_c0 = 4 * (rhs ? 8 * rr + 0 : 8 * cc + 0), src_c1 = 4 * (rhs ? 8 * rr + 1 : 8 * cc + 1);
+    // p(k+1)[i] comes from its lane for the right-hand-side lanes and from lane 63, which holds -0, for the others
+    int src_p[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) src_p[i] = 4 * (rhs ? 8 * (NU + i) + 7 : 63);
+    // P and p above the block's highest stage
+    pnew = (lane == 63) ? -0.0 : 0.0;
+    if (jinit >= 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double e = 0.0;
+                if (i == j) e = (i == 0) ? t.Ht[2] + t.hxx : (i == 1) ? t.Ht[3] + t.hyy : t.Ht[NU + i];
+                else if (i == 1 && j == 0) e = t.hxy;
+                const double v = bcast(e, jinit);
+                pnew = (rr == NU + i && cc == NU + j) ? v : pnew;
+            }
+            const double g = bcast(t.gt[NU + i], jinit);
+            pnew = (rr == NU + i && cc == 7) ? g : pnew;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) pnew = (rr == NU + i && cc == NU + j) ? cP[tri(i, j)] : pnew;
+            pnew = (rr == NU + i && cc == 7) ? cp[i] : pnew;
+        }
+    }
+    for (int khi = nst - 1; khi >= 0; khi -= CH) {
+        const int klo = (khi - CH + 1 > 0) ? khi - CH + 1 : 0;
+        lds_order();
+        if (lane >= klo && lane <= khi) {
+            ldouble *w = stg + (lane - klo) * SPR_REC;
+            w[0] = t.ab.a02; w[1] = t.ab.a03; w[2] = t.ab.a04; w[3] = t.ab.a12; w[4] = t.ab.a13; w[5] = t.ab.a14;
+            w[6] = t.ab.a23; w[7] = t.ab.a24; w[8] = t.ab.b00; w[9] = t.ab.b10; w[10] = t.ab.b20; w[11] = t.ab.b01;
+            w[12] = t.ab.b11; w[13] = t.ab.b21;
+            w[14] = hB; w[15] = 0.0; w[16] = 1.0;
+#pragma unroll
+            for (int q = 0; q < NZ; ++q) w[17 + q] = (q == 2) ? t.Ht[2] + t.hxx : (q == 3) ? t.Ht[3] + t.hyy : t.Ht[q];
+            w[24] = t.hxy;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) w[25 + i] = t.rb[i];
+#pragma unroll
+            for (int q = 0; q < NZ; ++q) w[30 + q] = t.gt[q];
+        }
+        lds_order();
+        lchar *base = (lchar *)stg + (khi - klo) * SPR_REC * 8;
+        double bc[NX], br[NX], ht;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { bc[i] = *(const ldouble *)(base + oc[i]); br[i] = *(const ldouble *)(base + orr[i]); }
+        ht = *(const ldouble *)(base + off_h);
+        for (int k = khi; k >= klo; --k) {
+            // the operands of the next stage are fetched while this one computes (reading them at the top of
+            // their own step instead, behind the broadcast of P, measured 2 % of an iteration slower)
+            double nbc[NX], nbr[NX], nht;
+            const lchar *nb = (k > klo) ? base - SPR_REC * 8 : base;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { nbc[i] = *(const ldouble *)(nb + oc[i]); nbr[i] = *(const ldouble *)(nb + orr[i]); }
+            nht = *(const ldouble *)(nb + off_h);
+            if (SUM) sum = lane_above<true>(sum, 0.0) + t.ssum;
+            double pn[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) pn[i] = spr_perm(src_p[i], pnew);
+            double P[15];
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) P[tri(i, j)] = bcast(pnew, 8 * (NU + i) + (NU + j));
+            double pba[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double acc = psym(P, i, 0) * bc[0];
+#pragma unroll
+                for (int j = 1; j < NX; ++j) acc = fma(psym(P, i, j), bc[j], acc);
+                pba[i] = pn[i] + acc;      // (adding -0 changes no number)
+            }
+            double m = ht;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) m = fma(br[i], pba[i], m);
+            const double m00 = bcast(m, 0), m10 = bcast(m, 8), m11 = bcast(m, 9);
+            const double mr0 = spr_perm(src_r0, m), mr1 = spr_perm(src_r1, m), mc0 = spr_perm(src_c0, m),
+                         mc1 = spr_perm(src_c1, m);
+            __builtin_amdgcn_sched_barrier(0);      // (the exchanges are under way while the pivots are inverted)
+            const double d0 = 1.0 / m00;
+            const double l10 = m10 * d0;
+            const double d1 = 1.0 / fma(-l10, m10, m11);
+            const double y1 = fma(-l10, mc0, mc1);
+            const double z0 = mc0 * d0, z1 = y1 * d1;
+            const double s0 = fma(-l10, z1, z0);
+            const double k0j = -s0, k1j = -z1;
+            const double e = fma(mr0, k0j, m);
+            const double pk = fma(mr1, k1j, e);
+            pnew = (lane == 63) ? -0.0 : pk;
+            *(ldouble *)(base + oA) = diag ? k0j : kvl ? m : l10;
+            *(ldouble *)(base + oB) = diag ? k1j : (lane == 1) ? d1 : d0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { bc[i] = nbc[i]; br[i] = nbr[i]; }
+            ht = nht;
+            base -= SPR_REC * 8;
+        }
+        lds_order();
+        if (lane >= klo && lane <= khi) {
+            const ldouble *w = stg + (lane - klo) * SPR_REC;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { ro.K[0][i] = w[i]; ro.K[1][i] = w[5 + i]; }
+            ro.l10 = w[10]; ro.d0 = w[11]; ro.d1 = w[12]; ro.kv[0] = w[13]; ro.kv[1] = w[14];
+        }
+    }
+    lds_order();
+}
+
+
 // one block of 64 consecutive stages (k0 .. k0+63) of sweep B0; what the block above handed
 // down, and the running reductions, are read from and left in the carry words
 template <int NH, bool ONE>
 __device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, gopts *op, bool sp_have, int sp_mode,
-                                                        double sp_sigma_mu, double sp_alpha, int k0, ldouble *ret)
+                                                        double sp_sigma_mu, double sp_alpha, int k0_spread, ldouble *ret)
 {
     COOP_UNPACK(NH);
     const mpcx_opts ol = opts_in_registers(op);
     const mpcx_opts &o = ol;
+    const int k0 = k0_spread & 0x3fffffff;
+    const bool spread = ((k0_spread >> 30) & 1) != 0;      // (bit 30: the recursion spread over the lanes, not as a pipeline)
     Step sp;
     sp.have = sp_have; sp.mode = sp_mode; sp.sigma_mu = sp_sigma_mu; sp.alpha = sp_alpha;
     const int N = __builtin_amdgcn_readfirstlane(C.N);      // (the same in every lane: loop counts in scalar registers)
     const int j = (int)threadIdx.x;
-    ldouble *carry = ret - j + 5 * 64;      // same address in every lane
+    ldouble *carry = ret - j + Spr<NH>::CARRY;      // same address in every lane
     const int kj = k0 + j;
     const Lane S = stage_lane(C, (unsigned)kj);
     // the stage above supplies its updated state and multiplier: the lane above, or the
@@ -2404,8 +2604,24 @@ __device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, gopts *op, 
         carry[CY_NORM + 0] = ng; carry[CY_NORM + 1] = nb; carry[CY_NORM + 2] = nd; carry[CY_NORM + 3] = nm;
         carry[CY_NORM + 4] = sum;
     }
-    double Po[15], po[NX];
     RicOut ro = {};
+    if (spread) {
+        // (the staging area is the result slots and what follows them: nothing of this sweep is there yet)
+        double pk, none = 0.0;
+        ric_spread<Spr<NH>::CH_BLOCK, false>(t, S.hB, steps, (N - k0 < 64) ? N - k0 : -1, cP, cp, ret - j, ro, none, pk);
+        if (kj < N) feed_forward(ro.l10, ro.d0, ro.d1, ro.kv[0], ro.kv[1], ro.kv);
+        SUB_END(18);
+        // P and p of the block's lowest stage, each entry from the lane that holds it
+        int cw = -1;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+#pragma unroll
+            for (int jj = 0; jj <= i; ++jj) cw = (j == 8 * (NU + i) + NU + jj) ? CY_P + tri(i, jj) : cw;
+            cw = (j == 8 * (NU + i) + 7) ? CY_PV + i : cw;
+        }
+        if (cw >= 0) carry[cw] = pk;
+    } else {
+    double Po[15], po[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) po[i] = 0.0;
 #pragma unroll
@@ -2431,24 +2647,26 @@ __device__ __attribute__((noinline)) void coop_B0_block(COOP_PARAMS, gopts *op, 
 #pragma unroll
         for (int i = 0; i < NX; ++i) carry[CY_PV + i] = po[i];
     }
+    }
     lds_order();
     if (kj < N) store_ric<NH, ANY>(S, 0, true, ro);
     SUB_END(19);
 }
 
 template <int NH>
-DEV void coop_B0(const Lane &C, const PC<NH> &pc, gopts *op, const Step &sp, int m_total, ldouble *ret)
+DEV void coop_B0(const Lane &C, const PC<NH> &pc, gopts *op, const Step &sp, int m_total, int spread_on, ldouble *ret)
 {
+    const int sb = spread_on ? (1 << 30) : 0;
     const int N = __builtin_amdgcn_readfirstlane(C.N);      // (the same in every lane: loop counts in scalar registers)
-    ldouble *carry = ret - threadIdx.x + 5 * 64;
+    ldouble *carry = ret - threadIdx.x + Spr<NH>::CARRY;
     if (threadIdx.x < CY_N) carry[threadIdx.x] = 0.0;
     lds_order();
     // blocks of 64 consecutive stages, the last block first
     if (N < 64) {      // a single block: everything handed down from above is zero
-        coop_B0_block<NH, true>(COOP_PASS(C, pc), op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, 0, ret);
+        coop_B0_block<NH, true>(COOP_PASS(C, pc), op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, sb, ret);
     } else {
         for (int k0 = (N / 64) * 64; k0 >= 0; k0 -= 64)
-            coop_B0_block<NH, false>(COOP_PASS(C, pc), op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, k0, ret);
+            coop_B0_block<NH, false>(COOP_PASS(C, pc), op, sp.have, sp.mode, sp.sigma_mu, sp.alpha, k0 | sb, ret);
     }
     lds_order();
     const double ng = carry[CY_NORM + 0], nb = carry[CY_NORM + 1], nd = carry[CY_NORM + 2], nm = carry[CY_NORM + 3],
@@ -2592,185 +2810,6 @@ enum { BR_STATE = 0, BR_STATUS, BR_ADD_TOTAL, BR_ADD_SQP, BR_QIT, BR_HAVE, BR_MO
 static_assert(BR_N <= CY_N, "burst results fit the carry words");
 static_assert(MPCX_STORE_RECIP == 0, "the resident burst keeps the slack reciprocals in registers itself");
 
-// ---------------------------------------------------------------------------
-// The backward Riccati recursion of a burst -- factors and the affine backward substitution -- with the
-// algebra of ONE stage spread over the lanes instead of a lane pipeline over the stages.
-//
-// The lane pipelines execute a stage's ~390 instructions in every lane for one useful lane a step.  Here the
-// stages are taken in turn, N down to 0, and lane 8 r + c, r < 7, owns entry (r, c) of
-// M = Ht + [B A]' P(k+1) [B A] for c < 7 and entry r of the right-hand side m = gt + [B A]' (p(k+1) + P(k+1) rb)
-// for c = 7: P(k+1) travels as 15 wave-uniform values (v_readlane), p(k+1) reaches the right-hand-side lanes by
-// ds_bpermute (the other lanes read -0 from lane 63 in the same instruction), every lane forms its column of
-// P(k+1) [B A] (the right-hand-side lanes: P(k+1) rb, then + p(k+1)) and its entry with five multiply-adds
-// each, every lane factorises the 2 x 2 input block itself, and one multiply-add pair gives entry (r, c) of
-// P(k) = M_xx + M_xu K in the entry lanes and entry r of p(k) = m_x + K' m_u in the right-hand-side lanes (the
-// same two instructions on other exchange partners).  Every number is produced by the operations of
-// stage_B0_ric() in their order: the dense chains here contain the pattern chains there, and a multiplication
-// by a structural 1 or an addition of a structural 0 product leaves a finite number as it is.
-//
-// The operands of a stage are uniform per step, so they come from LDS: the stage's own lane writes a record
-// of SPR_REC doubles (word 37 takes the stores of lanes that have no result; [0,14) the pattern entries of A and B; 14 hB; 15 zero; 16 one; [17,24) the diagonal of the
-// barrier Hessian, the (x, y) block's added; 24 its off-diagonal entry; [25,30) rb; [30,37) gt), CH stages at
-// a time (CH), and takes the results back from it ([0,5) K row 0; [5,10) K row 1; 10 l10; 11, 12 the reciprocal
-// pivots; 13, 14 the input part of the right-hand side).  `stg` is the wavefront's staging area of
-// CH * SPR_REC doubles.  The complementarity sum rides along as before, one pipeline step per stage.
-// ---------------------------------------------------------------------------
-#define SPR_REC 38
-// Doubles of LDS per wavefront beyond the result slots and carry words (which the staging area also covers), and the
-// stages staged at a time: what is left of 40 KB -- four workgroups on a compute unit -- beside the problem
-// constants, which grow with the obstacle rows; with four obstacles three workgroups fit anyway.
-template <int NH> struct Spr {
-    static constexpr int EXTRA = (NH == 0 || NH == 4) ? 704 : 5120 - (PCN<NH>::N + 6) * 64;
-    static constexpr int CH = ((6 * 64 + EXTRA) / SPR_REC > 25) ? 25 : (6 * 64 + EXTRA) / SPR_REC;
-    static_assert(EXTRA >= 0 && CH >= 8, "staging area");
-};
-
-DEV int spr_word(int c, int j)      // word of entry (j, c) of [B A | rb] in a staging record
-{
-    switch (c) {
-    case 0: return (j == 0) ? 8 : (j == 1) ? 9 : (j == 2) ? 10 : (j == 3) ? 14 : 15;
-    case 1: return (j == 0) ? 11 : (j == 1) ? 12 : (j == 2) ? 13 : (j == 3) ? 15 : 14;
-    case 2: return (j == 0) ? 16 : 15;
-    case 3: return (j == 1) ? 16 : 15;
-    case 4: return (j == 0) ? 0 : (j == 1) ? 3 : (j == 2) ? 16 : 15;
-    case 5: return (j == 0) ? 1 : (j == 1) ? 4 : (j == 2) ? 6 : (j == 3) ? 16 : 15;
-    case 6: return (j == 0) ? 2 : (j == 1) ? 5 : (j == 2) ? 7 : (j == 3) ? 15 : 16;
-    default: return 25 + j;
-    }
-}
-DEV double spr_perm(int addr, double v)
-{
-    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
-    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-typedef __attribute__((address_space(3))) char lchar;
-
-template <int CH>
-DEV void burst_ric_spread(const B0Out &t, double hB, int N, ldouble *stg, RicOut &ro, double &sum)
-{
-    const int lane = (int)threadIdx.x;
-    const int r = lane >> 3, c = lane & 7;
-    const bool ent = r < NZ;
-    const bool rhs = ent && c == 7;
-    const int rr = ent ? r : 0, cc = ent ? c : 0;      // (lanes without an entry run along on entry (0, 0))
-    unsigned oc[NX], orr[NX];
-#pragma unroll
-    for (int j = 0; j < NX; ++j) { oc[j] = 8u * (unsigned)spr_word(cc, j); orr[j] = 8u * (unsigned)spr_word(rr, j); }
-    const unsigned off_h = (cc == 7) ? 8u * (unsigned)(30 + rr)
-                                     : 8u * (unsigned)((rr == cc) ? 17 + rr : (rr == 3 && cc == 2) ? 24 : 15);
-    // where a lane's two results of a step go in the record: the diagonal lanes (NU+j, NU+j) have column j of K,
-    // lanes 0 and 1 the pivots, the lanes (0, 7), (1, 7) the input part of the right-hand side; the rest word 37
-    const bool diag = ent && cc < 7 && rr == cc && rr >= NU;
-    const bool kvl = rhs && rr < NU;
-    const unsigned oA = 8u * (unsigned)(diag ? (cc - NU) : (lane == 0) ? 10 : kvl ? 13 + rr : 37);
-    const unsigned oB = 8u * (unsigned)(diag ? (5 + cc - NU) : (lane == 0) ? 11 : (lane == 1) ? 12 : 37);
-    // exchange partners.  Entry lanes: M[r][0], M[r][1] of the row and M[c][0], M[c][1] of the column.
-    // Right-hand-side lanes: m[0], m[1], and M[r][0], M[r][1] of the row
-    const int src_r0 = 4 * (rhs ? 8 * 0 + 7 : 8 * rr + 0), src_r1 = 4 * (rhs ? 8 * 1 + 7 : 8 * rr + 1);
-    const int src_c0 = 4 * (rhs ? 8 * rr + 0 : 8 * cc + 0), src_c1 = 4 * (rhs ? 8 * rr + 1 : 8 * cc + 1);
-    // p(k+1)[i] comes from its lane for the right-hand-side lanes and from lane 63, which holds -0, for the others
-    int src_p[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) src_p[i] = 4 * (rhs ? 8 * (NU + i) + 7 : 63);
-    // P(N), p(N): the barrier Hessian and the gradient of the last stage, from its lane
-    double pnew = (lane == 63) ? -0.0 : 0.0;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            double e = 0.0;
-            if (i == j) e = (i == 0) ? t.Ht[2] + t.hxx : (i == 1) ? t.Ht[3] + t.hyy : t.Ht[NU + i];
-            else if (i == 1 && j == 0) e = t.hxy;
-            const double v = bcast(e, N);
-            pnew = (rr == NU + i && cc == NU + j) ? v : pnew;
-        }
-        const double g = bcast(t.gt[NU + i], N);
-        pnew = (rr == NU + i && cc == 7) ? g : pnew;
-    }
-    for (int khi = N - 1; khi >= 0; khi -= CH) {
-        const int klo = (khi - CH + 1 > 0) ? khi - CH + 1 : 0;
-        lds_order();
-        if (lane >= klo && lane <= khi) {
-            ldouble *w = stg + (lane - klo) * SPR_REC;
-            w[0] = t.ab.a02; w[1] = t.ab.a03; w[2] = t.ab.a04; w[3] = t.ab.a12; w[4] = t.ab.a13; w[5] = t.ab.a14;
-            w[6] = t.ab.a23; w[7] = t.ab.a24; w[8] = t.ab.b00; w[9] = t.ab.b10; w[10] = t.ab.b20; w[11] = t.ab.b01;
-            w[12] = t.ab.b11; w[13] = t.ab.b21;
-            w[14] = hB; w[15] = 0.0; w[16] = 1.0;
-#pragma unroll
-            for (int q = 0; q < NZ; ++q) w[17 + q] = (q == 2) ? t.Ht[2] + t.hxx : (q == 3) ? t.Ht[3] + t.hyy : t.Ht[q];
-            w[24] = t.hxy;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) w[25 + i] = t.rb[i];
-#pragma unroll
-            for (int q = 0; q < NZ; ++q) w[30 + q] = t.gt[q];
-        }
-        lds_order();
-        lchar *base = (lchar *)stg + (khi - klo) * SPR_REC * 8;
-        double bc[NX], br[NX], ht;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { bc[i] = *(const ldouble *)(base + oc[i]); br[i] = *(const ldouble *)(base + orr[i]); }
-        ht = *(const ldouble *)(base + off_h);
-        for (int k = khi; k >= klo; --k) {
-            // the operands of the next stage are fetched while this one computes (reading them at the top of
-            // their own step instead, behind the broadcast of P, measured 2 % of an iteration slower)
-            double nbc[NX], nbr[NX], nht;
-            const lchar *nb = (k > klo) ? base - SPR_REC * 8 : base;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) { nbc[i] = *(const ldouble *)(nb + oc[i]); nbr[i] = *(const ldouble *)(nb + orr[i]); }
-            nht = *(const ldouble *)(nb + off_h);
-            sum = lane_above<true>(sum, 0.0) + t.ssum;
-            double pn[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) pn[i] = spr_perm(src_p[i], pnew);
-            double P[15];
-#pragma unroll
-            for (int i = 0; i < NX; ++i)
-#pragma unroll
-                for (int j = 0; j <= i; ++j) P[tri(i, j)] = bcast(pnew, 8 * (NU + i) + (NU + j));
-            double pba[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double acc = psym(P, i, 0) * bc[0];
-#pragma unroll
-                for (int j = 1; j < NX; ++j) acc = fma(psym(P, i, j), bc[j], acc);
-                pba[i] = pn[i] + acc;      // (adding -0 changes no number)
-            }
-            double m = ht;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) m = fma(br[i], pba[i], m);
-            const double m00 = bcast(m, 0), m10 = bcast(m, 8), m11 = bcast(m, 9);
-            const double mr0 = spr_perm(src_r0, m), mr1 = spr_perm(src_r1, m), mc0 = spr_perm(src_c0, m),
-                         mc1 = spr_perm(src_c1, m);
-            __builtin_amdgcn_sched_barrier(0);      // (the exchanges are under way while the pivots are inverted)
-            const double d0 = 1.0 / m00;
-            const double l10 = m10 * d0;
-            const double d1 = 1.0 / fma(-l10, m10, m11);
-            const double y1 = fma(-l10, mc0, mc1);
-            const double z0 = mc0 * d0, z1 = y1 * d1;
-            const double s0 = fma(-l10, z1, z0);
-            const double k0j = -s0, k1j = -z1;
-            const double e = fma(mr0, k0j, m);
-            const double pk = fma(mr1, k1j, e);
-            pnew = (lane == 63) ? -0.0 : pk;
-            *(ldouble *)(base + oA) = diag ? k0j : kvl ? m : l10;
-            *(ldouble *)(base + oB) = diag ? k1j : (lane == 1) ? d1 : d0;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) { bc[i] = nbc[i]; br[i] = nbr[i]; }
-            ht = nht;
-            base -= SPR_REC * 8;
-        }
-        lds_order();
-        if (lane >= klo && lane <= khi) {
-            const ldouble *w = stg + (lane - klo) * SPR_REC;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) { ro.K[0][i] = w[i]; ro.K[1][i] = w[5 + i]; }
-            ro.l10 = w[10]; ro.d0 = w[11]; ro.d1 = w[12]; ro.kv[0] = w[13]; ro.kv[1] = w[14];
-        }
-    }
-    lds_order();
-}
-
 template <int NH>
 __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, gopts *op, int sp_have_mode,
                                                      double sp_sigma_mu, double sp_alpha, int m_total, int qit_max,
@@ -2792,7 +2831,7 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, gopts *op, int
     const bool on = kj <= N;
     const Lane S = stage_lane(C, (unsigned)kj);
     const KR kr = {kj == 0, kj == N};
-    ldouble *carry = ret - j + 5 * 64;      // same address in every lane
+    ldouble *carry = ret - j + Spr<NH>::CARRY;      // same address in every lane
     Step sp;
     sp.have = sp_have; sp.mode = sp_mode; sp.sigma_mu = sp_sigma_mu; sp.alpha = sp_alpha;
     // ---- this lane's stage ----
@@ -2868,7 +2907,8 @@ __device__ __attribute__((noinline)) void coop_burst(COOP_PARAMS, gopts *op, int
         }
         // ================= Riccati factorisation and the affine backward substitution =================
         if (spread) {
-            burst_ric_spread<Spr<NH>::CH>(t, S.hB, N, ret - j, ro, sum);
+            double pn0;
+            ric_spread<Spr<NH>::CH_BURST, true>(t, S.hB, N, N, nullptr, nullptr, ret - j, ro, sum, pn0);
         } else {
         if (kj == N) stage_B0_ric<LAST>(S, t, Po, po, Po, po, ro);
         // the factorisation down the lanes ...
@@ -3249,7 +3289,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
     // stage records of the [stage][field][lane] layout, then `slots` single-problem regions
     const size_t wave_doubles = (size_t)((N + 1) + slots * ((N + 64) / 64)) * M::F * 64;
 
-    // constants, 5 result slots, carry words, and the rest of the staging area of burst_ric_spread()
+    // constants, 5 result slots, the rest of the staging area of ric_spread(), carry words
     __shared__ double pc_lds[(PCN<NH>::N + 6) * 64 + Spr<NH>::EXTRA];
     PC<NH> pc;
     pc.p = (ldouble *)pc_lds + threadIdx.x;
@@ -3364,7 +3404,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
         const int mt = __builtin_amdgcn_readlane(m_total, p);
         int qit = __builtin_amdgcn_readlane(qp_it, p);
         int n_state = LS_QP, n_status = -1, add_total = 0, add_sqp = 0;
-        coop_B0<NH>(C, pcc, op, s, mt, ret);
+        coop_B0<NH>(C, pcc, op, s, mt, spread_on, ret);
         SUB_END(31);
         STAMP(12, true);
         const double Rg = uniform(ret[0 * 64]), Rb = uniform(ret[1 * 64]), Rd = uniform(ret[2 * 64]),
@@ -3437,7 +3477,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
         if (max_iters < 1) max_iters = 1;
         coop_burst<NH>(COOP_PASS(C, pcc), op, (have << 8) | (mode & 255), sgm, alp, mt,
                        (int)(((unsigned)spread_on << 30) | ((unsigned)max_iters << 16) | ((unsigned)qit0 & 0xffffu)), ret);
-        ldouble *carry = ret - threadIdx.x + 5 * 64;
+        ldouble *carry = ret - threadIdx.x + Spr<NH>::CARRY;
         const int n_state = (int)uniform(carry[BR_STATE]), n_status = (int)uniform(carry[BR_STATUS]),
                   add_total = (int)uniform(carry[BR_ADD_TOTAL]), add_sqp = (int)uniform(carry[BR_ADD_SQP]),
                   qit = (int)uniform(carry[BR_QIT]), done = (int)uniform(carry[BR_DONE]);
@@ -3851,7 +3891,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
                 budget -= k;
                 if (threadIdx.x == 0 && best >= 1000) MARK(23);
                 if (threadIdx.x == 0) {
-                    MARK_AGE(12, 1000, best); MARK_AGE(14, 2000, best); MARK_AGE(36, 4000, best); MARK_AGE(38, 8000, best);
+                    MARK_AGE(12, 13, 1000, best); MARK_AGE(14, 15, 2000, best); MARK_AGE(55, 57, 4000, best); MARK_AGE(59, 61, 8000, best);
                 }
                 for (int t = 0; t < k;) {
                     const int st = __builtin_amdgcn_readlane(state, p);

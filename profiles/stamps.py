@@ -52,17 +52,18 @@ marks_raw = cyc[:, mark_slots].copy()
 cyc[:, mark_slots] = 0
 # (time, age) pairs: first burst of a problem at least 1000 / 2000 / 4000 / 8000 iterations old; the end of a
 # problem of 5000 iterations or more with the time of its fetch and its index
-age_marks = {thr: (buf[:, w].astype(np.float64), buf[:, w + 1].astype(np.int64))
-             for thr, w in ((1000, 12), (2000, 14), (4000, 36), (8000, 38))}
+age_marks = {thr: (buf[:, w].astype(np.float64), buf[:, wa].astype(np.int64))
+             for thr, w, wa in ((1000, 12, 13), (2000, 14, 15), (4000, 55, 57), (8000, 59, 61))}
 long_end = (buf[:, 41].astype(np.float64), buf[:, 43].astype(np.int64), buf[:, 45].astype(np.float64), buf[:, 47].astype(np.int64))
-cyc[:, [6, 7, 18, 19]] = 0
-cnt[:, [6, 7, 18, 19]] = 0
+cyc[:, [6, 7]] = 0
+cnt[:, [6, 7]] = 0
+cnt[:, [27, 28, 29, 30, 31]] = 0
 cnt[:, [20, 21, 22, 23]] = 0
 last_out = (buf[:, 49].astype(np.float64), buf[:, 51].astype(np.int64), buf[:, 53].astype(np.float64))
 cnt[:, [24, 25, 26]] = 0
 # parts of the single-problem sweeps (already contained in slots 12..15)
 # bursts (N < 64): slot 12 holds whole bursts, lanes-sum / 64 = iterations + QP ends
-sub_slots = {16: "    burst: B0 rows + reductions", 17: "    burst: Riccati pipeline", 24: "    burst: F affine", 25: "    burst: Bs", 26: "    burst: F both",
+sub_slots = {16: "    burst / block: B0 rows + reductions", 17: "    burst: Riccati recursion (block: reductions)", 18: "    block: Riccati pipeline", 19: "    block: stores of the factors", 24: "    burst: F affine", 25: "    burst: Bs", 26: "    burst: F both",
              27: "    burst: loads at the start / step selection", 28: "    sweep L, single-problem form",
              29: "    move to a region", 30: "    burst: stores at the end", 31: "    separate sweeps: B0"}
 sub_raw = {k: cyc[used, k].sum() for k in sub_slots}

@@ -81,8 +81,8 @@ def assert_same_solution(gpu, ref, what=""):
     assert ((a == b) | (np.isnan(a) & np.isnan(b))).all(), f"{what}: residuals differ"
 
 
-def obstacle_problems(B, duration, seed=5):
-    """Random start/goal pairs with one or two obstacles near the straight path (a synthetic
+def obstacle_problems(B, duration, seed=5, max_obs=2):
+    """Random start/goal pairs with one to `max_obs` obstacles near the straight path (a synthetic
     mix: the reference's only obstacle case is the path_finder demo above)."""
     rng = np.random.default_rng(seed)
     sim = SimConfig()
@@ -98,7 +98,7 @@ def obstacle_problems(B, duration, seed=5):
         e.state_start = list(s)
         e.state_final = list(g)
         obs = []
-        for j in range(1 + b % 2):
+        for j in range(1 + b % max_obs):
             t = rng.uniform(0.3, 0.7)
             off = rng.choice([-1.0, 1.0]) * rng.uniform(0.5, 2.0)
             obs.append([s[0] + t * (g[0] - s[0]) - off * np.sin(phi), s[1] + t * (g[1] - s[1]) + off * np.cos(phi),

@@ -267,6 +267,24 @@ def test_burst_lengths_leave_no_trace(oracle, monkeypatch, burst):
         cases.assert_same_solution(gpu, ref, f"burst={burst} B={B}")
 
 
+@pytest.mark.parametrize("spread", ["0", "1"])
+def test_spread_recursion_leaves_no_trace(oracle, monkeypatch, spread):
+    """The Riccati recursion of a burst as two lane pipelines (0) or with the algebra of one stage spread
+    over the lanes (1, the default; its staging area holds 25 / 23 / 18 / 13 / 25 stages at a time with 0..4
+    obstacle rows): the same bits as the oracle both ways, on batches small enough to be solved in bursts
+    throughout, with horizons below one staging chunk, of two chunks and at the last size a burst takes."""
+    monkeypatch.setenv("MPCX_SPREAD", spread)
+    batches = [("synthetic", synthetic_batch(48, seed=31)), ("reachable", reachable_batch(600, seed=32))]
+    for k in (1, 2, 3, 4):
+        batches.append((f"up to {k} obstacles", pack_problems(*cases.obstacle_problems(64, 5.0, seed=40 + k, max_obs=k))))
+    for duration in (0.2, 2.0, 6.3):
+        batches.append((f"N={int(duration / 0.1)}", pack_problems(*cases.obstacle_problems(48, duration, seed=50, max_obs=1))))
+    for name, packed in batches:
+        gpu = _lib.solve_packed(packed)
+        ref = oracle.solve_packed(packed)
+        cases.assert_same_solution(gpu, ref, f"spread={spread} {name}")
+
+
 @pytest.mark.parametrize("lanes", [None, 3, 20, 64])
 def test_rti_server_matches_oracle(oracle, monkeypatch, lanes):
     """Three receding-horizon ticks of a fleet: what the device solves each tick equals the
