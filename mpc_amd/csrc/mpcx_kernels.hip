@@ -24,9 +24,11 @@
 //      F   forward : both steps and their lengths (the centring-only one is taken
 //                    when the corrector would shorten the step)
 //
-//  * one lane per STAGE of a single problem (few problems left in the wavefront, small
-//    batches, long horizons): the rows of 64 stages are computed at once and the
-//    recursions run as a pipeline over the lanes; see "single-problem mode" below.
+//  * one lane per STAGE of a single problem (old problems, few problems left in the
+//    wavefront, small batches, long horizons): the rows of 64 stages are computed at once;
+//    the recursions run as pipelines over the lanes, except the Riccati recursion itself
+//    (factors and affine substitution), whose stages are taken in turn with the algebra of
+//    one stage spread over the lanes (ric_spread); see "single-problem mode" below.
 //
 // Both modes perform the same operations in the same order for a problem.
 //
