@@ -61,6 +61,7 @@ constexpr int kWavesPerCU = 4;    // resident wavefronts per CU the kernel's reg
 struct Plan { int waves, lanes, coop_max, lin_max, coop_layout; };
 constexpr int kLinMax = 0;
 constexpr int kCoopMax = 8;     // problems per wavefront up to which the single-problem sweeps pay
+constexpr int kCoopMaxRti = 16; // ... in a real-time iteration (a handful of iterations per problem, all in bursts; measured 8..32)
 constexpr int kSlots = 8;        // regions per wavefront for problems worked on in single-problem mode only
 constexpr int kPlanWaves = 1024;   // one wavefront per SIMD of 256 CUs; more would only wait for a slot
 
@@ -103,7 +104,8 @@ Plan plan_for(int B, int N, size_t target, bool rti = false)
     // One linearisation and one QP per problem (real-time iteration): all problems take about the
     // same few iterations, so once there are too many per wavefront for single-problem mode the
     // one-lane-per-problem sweeps are best run full (a sweep costs the same with 16 lanes as with 64).
-    if (rti && p.lanes > kCoopMax) p.lanes = 64;
+    const int coop_default = rti ? kCoopMaxRti : kCoopMax;
+    if (rti && p.lanes > coop_default) p.lanes = 64;
     // diagnostic knob: MPCX_LANES=n fixes the problems per wavefront (tests use it to run
     // small batches through the one-lane-per-problem sweeps)
     if (const char *e = std::getenv("MPCX_LANES")) {
@@ -112,7 +114,7 @@ Plan plan_for(int B, int N, size_t target, bool rti = false)
     }
     if (p.lanes < 1) p.lanes = 1;
     if (p.lanes > 64) p.lanes = 64;
-    p.coop_max = kCoopMax;
+    p.coop_max = coop_default;
     if (const char *e = std::getenv("MPCX_COOP_MAX")) {      // diagnostic knob, 0 switches the mode off
         const int v = std::atoi(e);
         if (v >= 0 && v <= 64) p.coop_max = v;
