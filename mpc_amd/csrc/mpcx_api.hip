@@ -64,6 +64,11 @@ constexpr int kCoopMax = 8;     // problems per wavefront up to which the single
 constexpr int kCoopMaxRti = 16; // ... in a real-time iteration (a handful of iterations per problem, all in bursts; measured 8..32)
 constexpr int kSlots = 8;        // regions per wavefront for problems worked on in single-problem mode only
 constexpr int kPlanWaves = 1024;   // one wavefront per SIMD of 256 CUs; more would only wait for a slot
+// Up to this many problems a full solve is fastest with ONE problem at a time per wavefront, each wavefront
+// taking the next from the queue when its problem ends (single-problem mode throughout, no problem waits for
+// a neighbour's bursts; measured against 2..64 per wavefront: 16 384 problems 81 -> 45 ms, 65 536 121 -> 118 ms,
+// 131 072 256 -> 304 ms)
+constexpr int kOneAtATimeMax = 65536;
 
 size_t default_workspace_target()
 {
@@ -106,6 +111,7 @@ Plan plan_for(int B, int N, size_t target, bool rti = false)
     // one-lane-per-problem sweeps are best run full (a sweep costs the same with 16 lanes as with 64).
     const int coop_default = rti ? kCoopMaxRti : kCoopMax;
     if (rti && p.lanes > coop_default) p.lanes = 64;
+    if (!rti && B <= kOneAtATimeMax) p.lanes = 1;
     // diagnostic knob: MPCX_LANES=n fixes the problems per wavefront (tests use it to run
     // small batches through the one-lane-per-problem sweeps)
     if (const char *e = std::getenv("MPCX_LANES")) {
