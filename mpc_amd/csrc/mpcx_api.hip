@@ -111,7 +111,9 @@ Plan plan_for(int B, int N, size_t target, bool rti = false)
     // one-lane-per-problem sweeps are best run full (a sweep costs the same with 16 lanes as with 64).
     const int coop_default = rti ? kCoopMaxRti : kCoopMax;
     if (rti && p.lanes > coop_default) p.lanes = 64;
-    if (!rti && B <= kOneAtATimeMax) p.lanes = 1;
+    // (when the workspace holds a wavefront per SIMD, or one per problem; a small workspace -- the static one, a
+    // caller's own -- is better used by full wavefronts)
+    if (!rti && B <= kOneAtATimeMax && (cap >= (size_t)kPlanWaves || cap >= (size_t)B)) p.lanes = 1;
     // diagnostic knob: MPCX_LANES=n fixes the problems per wavefront (tests use it to run
     // small batches through the one-lane-per-problem sweeps)
     if (const char *e = std::getenv("MPCX_LANES")) {
