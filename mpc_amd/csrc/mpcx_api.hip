@@ -60,6 +60,7 @@ constexpr int kWavesPerCU = 4;    // resident wavefronts per CU the kernel's reg
 // for a GPU with 288 GB, and the host entry point falls back to less if the allocation fails).
 struct Plan { int waves, lanes, coop_max, lin_max, coop_layout; };
 constexpr int kLinMax = 0;
+constexpr size_t kHeader = MPCX_WS_HEADER_BYTES;      // problem counter, options, hand-over area
 constexpr int kCoopMax = 8;     // problems per wavefront up to which the single-problem sweeps pay
 constexpr int kCoopMaxRti = 16; // ... in a real-time iteration (a handful of iterations per problem, all in bursts; measured 8..32)
 constexpr int kSlots = 8;        // regions per wavefront for problems worked on in single-problem mode only
@@ -265,7 +266,7 @@ int mpcx_static_max_horizon(void)
         int lo = 0, hi = 1 << 20;
         while (lo < hi) {
             const int mid = lo + (hi - lo + 1) / 2;
-            if (512 + wave_bytes(mid, MPCX_MAX_OBS) <= (size_t)MPCX_STATIC_SCRATCH_BYTES) lo = mid; else hi = mid - 1;
+            if (kHeader + wave_bytes(mid, MPCX_MAX_OBS) <= (size_t)MPCX_STATIC_SCRATCH_BYTES) lo = mid; else hi = mid - 1;
         }
         return lo;
     }();
@@ -275,7 +276,7 @@ int mpcx_static_max_horizon(void)
 int mpcx_static_max_wavefronts(int32_t N)
 {
     if (N < 1 || N > mpcx_static_max_horizon()) return 0;
-    const size_t w = ((size_t)MPCX_STATIC_SCRATCH_BYTES - 512) / wave_bytes(N, MPCX_MAX_OBS);
+    const size_t w = ((size_t)MPCX_STATIC_SCRATCH_BYTES - kHeader) / wave_bytes(N, MPCX_MAX_OBS);
     return (int)(w < (size_t)kPlanWaves ? w : (size_t)kPlanWaves);
 }
 
@@ -289,7 +290,7 @@ int mpcx_device_count(void)
 size_t mpcx_workspace_bytes(int32_t B, int32_t N)
 {
     if (B <= 0 || N < 1) return 0;
-    return 512 + (size_t)plan_for(B, N, default_workspace_target()).waves * wave_bytes(N, MPCX_MAX_OBS);
+    return kHeader + (size_t)plan_for(B, N, default_workspace_target()).waves * wave_bytes(N, MPCX_MAX_OBS);
 }
 
 int mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *out,
@@ -301,10 +302,10 @@ int mpcx_solve_batch_device(const mpcx_batch *in, const mpcx_opts *opts, mpcx_re
     const int nh = (opts->max_obs < 0) ? MPCX_MAX_OBS : opts->max_obs;
     // the batch is spread as far as the given workspace allows (mpcx_workspace_bytes() is the
     // size that allows the widest useful spread); one wavefront's worth is the minimum
-    const size_t least = 512 + wave_bytes(in->N, MPCX_MAX_OBS);
+    const size_t least = kHeader + wave_bytes(in->N, MPCX_MAX_OBS);
     if (!workspace || workspace_bytes < least)
         return fail(MPCX_E_BADARG, "workspace too small: %zu bytes given, at least %zu needed", workspace_bytes, least);
-    const Plan plan = plan_for(in->B, in->N, workspace_bytes - 512, opts->rti != 0);
+    const Plan plan = plan_for(in->B, in->N, workspace_bytes - kHeader, opts->rti != 0);
     if ((uintptr_t)workspace % 256 != 0) return fail(MPCX_E_BADARG, "workspace not 256-byte aligned");
     HIP_TRY(mpcx_launch_sqp(nh, *in, *opts, *out, static_cast<double *>(workspace), waves_to_launch(plan), plan.lanes, plan.coop_max, plan.lin_max, plan.coop_layout, kSlots,
                             static_cast<hipStream_t>(stream)));
@@ -341,7 +342,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     size_t ws_bytes = 0;
     for (size_t target = default_workspace_target();; target /= 2) {
         plan = plan_for(in->B, in->N, target, o.rti != 0);
-        ws_bytes = 512 + (size_t)plan.waves * wave_bytes(in->N, nh);
+        ws_bytes = kHeader + (size_t)plan.waves * wave_bytes(in->N, nh);
         if (d_ws.alloc(ws_bytes) == hipSuccess) break;
         (void)hipGetLastError();
         d_ws.p = nullptr;
@@ -541,7 +542,7 @@ int mpcx_ctx_solve(mpcx_ctx *c, const mpcx_batch *in, const mpcx_opts *opts, mpc
     size_t ws_bytes = 0;
     for (size_t target = default_workspace_target();; target /= 2) {
         plan = plan_for(in->B, in->N, target, o.rti != 0);
-        ws_bytes = 512 + (size_t)plan.waves * wave_bytes(in->N, nh);
+        ws_bytes = kHeader + (size_t)plan.waves * wave_bytes(in->N, nh);
         if (c->ws.ensure(ws_bytes) == hipSuccess) break;
         (void)hipGetLastError();
         if (plan.waves == 1 || target < ((size_t)1 << 28))
@@ -598,7 +599,7 @@ int mpcx_solve_batch_static(const mpcx_batch *in, const mpcx_opts *opts, mpcx_re
     if (int rc = check_call(in, opts, out)) return rc;
     if (in->B == 0) return 0;
     if (mpcx_device_count() <= 0) return fail(MPCX_E_NODEVICE, "no HIP device");
-    const size_t least = 512 + wave_bytes(in->N, MPCX_MAX_OBS);
+    const size_t least = kHeader + wave_bytes(in->N, MPCX_MAX_OBS);
     if (least > (size_t)MPCX_STATIC_SCRATCH_BYTES)
         return fail(MPCX_E_BADARG, "N = %d needs %zu bytes of workspace, the built-in scratch holds %zu: use "
                     "mpcx_solve_batch_device with a workspace of the caller's", in->N, least, (size_t)MPCX_STATIC_SCRATCH_BYTES);
@@ -612,7 +613,7 @@ int mpcx_solve_batch_static(const mpcx_batch *in, const mpcx_opts *opts, mpcx_re
         g_scratch_ptr[dev].store(ptr, std::memory_order_release);
     }
     const int nh = (opts->max_obs < 0) ? MPCX_MAX_OBS : opts->max_obs;
-    const Plan plan = plan_for(in->B, in->N, (size_t)MPCX_STATIC_SCRATCH_BYTES - 512, opts->rti != 0);
+    const Plan plan = plan_for(in->B, in->N, (size_t)MPCX_STATIC_SCRATCH_BYTES - kHeader, opts->rti != 0);
     hipStream_t q = static_cast<hipStream_t>(stream);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(q, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }

@@ -3281,7 +3281,7 @@ template <int NH>
 __global__ void __launch_bounds__(64) __attribute__((disable_tail_calls))
 mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
                 int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots, unsigned deal, int burst_few,
-                double hold_alpha, int hold_extra, int boost_mul, int spread_on)
+                double hold_alpha, int hold_extra, int boost_mul, int spread_on, unsigned char *ho, int n_workers, int ho_limit)
 {
     const mpcx_opts &o = *op_generic;
     gopts *op = (gopts *)op_generic;      // what the sweeps are handed
@@ -3504,6 +3504,27 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
     // only work on in single-problem mode from now on is moved to a free one (`solo` lane): the
     // last problems once the queue is empty, and old problems that get extra iterations.
     bool moved = false;          // the queue is empty and the last problems have been moved
+    // Hand-over of old problems (ho != nullptr).  A wavefront that finds one of its problems old moves it to one
+    // of its regions as before, but instead of giving it bursts itself it writes what the lane knows of the
+    // problem into a descriptor and queues the descriptor's number; the lane is free for the next problem.
+    // Worker wavefronts -- the last n_workers of the grid from the start, every other wavefront once its own
+    // problems are done -- take descriptors from the queue and run each problem to its end in bursts, on the
+    // region where it lies (the workspace pointer of the wavefront is that of the problem's first owner
+    // meanwhile).  So no problem waits for a neighbour's bursts, old problems are balanced over the wavefronts
+    // whatever wavefront fetched them, and the longest problem has a wavefront of its own from its 16th
+    // iteration on.  The workers of the first kind leave when the queue is empty and no wavefront that could still
+    // hand a problem over is left (a count of the wavefronts that have problems of their own, in the hand-over
+    // area); the others when they find the queue empty.
+    unsigned *const ho_head = (unsigned *)ho, *const ho_tail = (unsigned *)(ho ? ho + 128 : nullptr),
+                   *const ho_active = (unsigned *)(ho ? ho + 256 : nullptr), *const ho_ring = (unsigned *)(ho ? ho + MPCX_HO_RING : nullptr),
+                   *const ho_busy = (unsigned *)(ho ? ho + MPCX_HO_BUSY : nullptr);
+    double *const ho_desc = (double *)(ho ? ho + MPCX_HO_DESC : nullptr);
+    const bool born_worker = ho != nullptr && (int)blockIdx.x >= (int)gridDim.x - n_workers;
+    bool worker = born_worker;
+    int job = -1;                // worker: the descriptor it is working on
+    unsigned given = 0;          // slots of this wavefront whose problems are with a worker (same in all lanes)
+    gdouble *const own_wave = L.wave;
+    if (worker) state = LS_DONE;
     bool solo = false;           // this lane's problem lives in a region; the one-lane-per-problem sweeps skip it
     unsigned slot_used = 0;      // same in all lanes
     const unsigned rec_bytes = (unsigned)(M::F * 512), nblk = (unsigned)((N + 64) / 64);
@@ -3624,6 +3645,15 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
 #pragma unroll
                 for (int i = 0; i < 4; ++i) out.res[(size_t)i * L.B + b] = res[i];
                 state = LS_FETCH;
+            }
+            if (ho != nullptr && out_mask != 0) {
+                if (job >= 0) {      // a worker's problem has been written out: its first owner gets the region back
+                    if (threadIdx.x == 0) state = LS_DONE;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (threadIdx.x == 0) __hip_atomic_store(ho_busy + job, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    job = -1;
+                    L.wave = own_wave;
+                }
             }
             STAMP(8, st_e);
             [[maybe_unused]] const bool st_a = (state == LS_FETCH);
@@ -3767,15 +3797,101 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
             STAMP(1, st_b);
         }
         if (!__any(state != LS_DONE)) {
-            if (threadIdx.x == 0) MARK_LAST(22);
-            break;
+            if (ho == nullptr) {
+                if (threadIdx.x == 0) MARK_LAST(22);
+                break;
+            }
+            // nothing of its own left (and nothing more to hand over): the wavefront works on handed-over problems
+            if (!worker) {
+                worker = true;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (threadIdx.x == 0) atomicSub(ho_active, 1u);
+            }
+            int got = -1;
+            if (threadIdx.x == 0) {
+                const unsigned h = __hip_atomic_load(ho_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned t = __hip_atomic_load(ho_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(t - h) > 0) {
+                    unsigned expect = h;
+                    if (__hip_atomic_compare_exchange_strong(ho_head, &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT)) {
+                        // (the ring word follows the tail at once; a bounded wait all the same)
+                        unsigned v = 0;
+                        for (int spin = 0; spin < (1 << 20) && v == 0; ++spin) {
+                            v = __hip_atomic_load(ho_ring + (h & (MPCX_HANDOVER_SLOTS - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (v == 0) __builtin_amdgcn_s_sleep(8);
+                        }
+                        if (v != 0) {
+                            __hip_atomic_store(ho_ring + (h & (MPCX_HANDOVER_SLOTS - 1)), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            got = (int)v - 1;
+                        }
+                    }
+                }
+            }
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (got < 0) {
+                // The queue is empty.  A wavefront that was a worker from the start stays while any wavefront is left
+                // that could hand a problem over (the count is read first); the others have done their share and
+                // leave their place to whatever the device has waiting.
+                int over = 0;
+                if (threadIdx.x == 0) {
+                    const unsigned a = __hip_atomic_load(ho_active, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned h = __hip_atomic_load(ho_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned t = __hip_atomic_load(ho_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    over = ((a == 0u || !born_worker) && h == t) ? 1 : 0;
+                }
+                if (__builtin_amdgcn_readfirstlane(over) != 0) {
+                    if (threadIdx.x == 0) MARK_LAST(22);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(127);
+                continue;
+            }
+            // the problem moves into lane 0
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const double *d = ho_desc + (size_t)got * 32;
+            const int w = (int)d[20];
+            L.wave = (gdouble *)workspace + (size_t)w * wave_doubles;
+            job = got;
+            if (threadIdx.x == 0) {
+                L.b = (unsigned)d[0];
+                L.nobs = (int)d[1];
+                state = (int)d[2];
+                status = (int)d[3];
+                sqp_it = (int)d[4];
+                qp_it = (int)d[5];
+                qp_total = (int)d[6];
+                m_total = (int)d[7];
+                first = d[8] != 0.0;
+                sp.have = d[9] != 0.0;
+                sp.mode = (int)d[10];
+                sp.sigma_mu = d[11];
+                sp.alpha = d[12];
+                res[0] = d[13]; res[1] = d[14]; res[2] = d[15]; res[3] = d[16];
+                cost = d[17];
+                ls_rho = d[18];
+                L.roff = (unsigned)d[19];
+                solo = true;
+                fresh = false;
+#ifdef MPCX_STAMPS
+                t_fetch = 0;
+#endif
+                L.h = ldp(L, MPCX_F_H);
+                L.hh = 0.5 * L.h;
+                L.h6 = L.h / 6.0;
+                L.hB = L.h6 * 6.0;
+                L.invL = 1.0 / ldp(L, MPCX_F_L);
+                fill_pc<NH>(L, o, pc);
+            }
+            coop_sync();
+            continue;
         }
 
         // ---- few problems left: one interior-point iteration of each, the wavefront on one problem
         const unsigned long long qp_mask = __ballot(state == LS_QP);
         if (__popcll(qp_mask) <= coop_max || L.region != 0) {
             for (unsigned long long rest = qp_mask; rest != 0; rest &= rest - 1) {
-                if (N < 64 && burst_few > 0) (void)single_burst(__ffsll((long long)rest) - 1, burst_few);
+                if (N < 64 && burst_few > 0) (void)single_burst(__ffsll((long long)rest) - 1, (job >= 0) ? 4096 : burst_few);
                 else single_qp(__ffsll((long long)rest) - 1);
             }
             coop_sync();      // every single-problem sweep starts with one; this one is for the other mode
@@ -3884,7 +4000,56 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
                         if (a > best) { best = a; p = i; }
                     }
                     ++n_new;
-                    if (slots > 0 && L.region == 0) (void)move_to_region(p);
+                    // (handed over while the workers keep up: with ho_limit descriptors waiting the wavefront gives
+                    // the problem its bursts itself, as it would without workers)
+                    bool hand = ho != nullptr && job < 0 && slots > 0 && L.region == 0 && N < 64;
+                    if (hand) {
+                        int waiting = 0;
+                        if (threadIdx.x == 0)
+                            waiting = (int)(__hip_atomic_load(ho_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                                            __hip_atomic_load(ho_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        hand = __builtin_amdgcn_readfirstlane(waiting) < ho_limit;
+                    }
+                    if (hand) {
+                        // regions whose problems a worker has finished are free again
+                        if (given != 0) {
+                            const unsigned mine = (threadIdx.x < 32u && ((given >> threadIdx.x) & 1u))
+                                                      ? __hip_atomic_load(ho_busy + blockIdx.x * (unsigned)slots + threadIdx.x,
+                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                      : 1u;
+                            const unsigned back = (unsigned)__ballot(mine == 0u) & given;
+                            given &= ~back;
+                            slot_used &= ~back;
+                        }
+                        const unsigned before = slot_used;
+                        if (move_to_region(p) && slot_used != before) {
+                            const int slot = __ffs((int)(slot_used & ~before)) - 1;
+                            const int id = (int)blockIdx.x * slots + slot;
+                            if ((int)threadIdx.x == p) {
+                                double *d = ho_desc + (size_t)id * 32;
+                                d[0] = (double)L.b; d[1] = (double)L.nobs; d[2] = (double)state; d[3] = (double)status;
+                                d[4] = (double)sqp_it; d[5] = (double)qp_it; d[6] = (double)qp_total; d[7] = (double)m_total;
+                                d[8] = first ? 1.0 : 0.0; d[9] = sp.have ? 1.0 : 0.0; d[10] = (double)sp.mode;
+                                d[11] = sp.sigma_mu; d[12] = sp.alpha;
+                                d[13] = res[0]; d[14] = res[1]; d[15] = res[2]; d[16] = res[3];
+                                d[17] = cost; d[18] = ls_rho; d[19] = (double)L.roff; d[20] = (double)blockIdx.x;
+                                __hip_atomic_store(ho_busy + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                            if ((int)threadIdx.x == p) {
+                                const unsigned t = atomicAdd(ho_tail, 1u);
+                                __hip_atomic_store(ho_ring + (t & (MPCX_HANDOVER_SLOTS - 1)), (unsigned)id + 1u, __ATOMIC_RELEASE,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                                // the lane is free; the region stays taken until the worker is done with it
+                                state = LS_FETCH;
+                                solo = false;
+                                L.roff = 0;
+                            }
+                            given |= 1u << slot;
+                            seen |= 1ull << p;
+                            continue;
+                        }
+                    } else if (slots > 0 && L.region == 0) (void)move_to_region(p);
                 }
                 seen |= 1ull << p;
                 int k = (int)(((long long)best * boost_mul) / boost_div);
@@ -3921,10 +4086,13 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
 }
 
 // workspace header of a launch: problem counter (and the rest of its 256 bytes) zero, options behind it
-__global__ void mpcx_header_kernel(int *counter, mpcx_opts *d_opts, mpcx_opts o)
+// (and the counters, the ring and the busy words of the hand-over area)
+__global__ void mpcx_header_kernel(int *counter, mpcx_opts *d_opts, mpcx_opts o, unsigned n_own)
 {
-    counter[threadIdx.x] = 0;
+    if (threadIdx.x < 64) counter[threadIdx.x] = 0;
     if (threadIdx.x == 0) *d_opts = o;
+    unsigned *ho = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(counter) + 512);
+    for (unsigned i = threadIdx.x; i < MPCX_HO_DESC / 4; i += blockDim.x) ho[i] = (i == 64u) ? n_own : 0u;      // (byte 256: wavefronts with problems of their own)
 }
 
 // initial guess (reference core_solver.py:477-499, and :360-473 for problems with obstacles, up to
@@ -4023,17 +4191,31 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     // 1: the Riccati recursion of a burst with one stage's algebra spread over the lanes; 0: as lane pipelines
     int spread_on = 1;
     if (const char *e = getenv("MPCX_SPREAD")) spread_on = atoi(e) != 0;
+    // Hand-over of old problems to worker wavefronts (see the kernel): on when the grid is full wavefronts of 64
+    // problems (large batches) with bursts available; 5/16 of the wavefronts are workers from the start, and a
+    // wavefront keeps an old problem for itself while 64 descriptors wait (measured on 1 M problems: 128..512
+    // workers, limits 16..2048; the reachable and obstacle workloads and 131 072 / 262 144 problems beside the
+    // benchmark batch).  MPCX_HANDOVER="workers[,limit]" sets both, 0 switches the hand-over off.
+    int n_workers = (n_waves >= 256) ? (n_waves * 5) / 16 : 0, ho_limit = 64;
+    if (const char *e = getenv("MPCX_HANDOVER")) {      // (also on smaller grids: the tests)
+        int v = 0, l = 64;
+        if (sscanf(e, "%d,%d", &v, &l) >= 1 && v >= 0 && v < n_waves && l >= 1) { n_workers = v; ho_limit = l; }
+    }
+    const bool handover = n_workers > 0 && lanes == 64 && !o.rti && in.N < 64 && burst_few > 0 &&
+                          n_waves * slots <= MPCX_HANDOVER_SLOTS && coop_layout == 0 && coop_max > 0 && slots > 0;
+    unsigned char *ho = handover ? reinterpret_cast<unsigned char *>(workspace) + 512 : nullptr;
+    if (!handover) n_workers = 0;
     int svc_min = MPCX_SERVICE_MIN;
     if (const char *e = getenv("MPCX_SVC_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) svc_min = v; }
     if (coop_max < 0 || coop_max > 64) return hipErrorInvalidValue;
     if (lanes < 1 || lanes > 64 || n_waves < 1) return hipErrorInvalidValue;
-    // workspace header (512 bytes): problem counter at byte 0, the options at byte 256
+    // workspace header: problem counter at byte 0, the options at byte 256, the hand-over area from byte 512
     static_assert(sizeof(mpcx_opts) <= 256, "options must fit the workspace header");
     int *counter = reinterpret_cast<int *>(workspace);
     mpcx_opts *d_opts = reinterpret_cast<mpcx_opts *>(reinterpret_cast<char *>(workspace) + 256);
-    double *ws = workspace + 64;
+    double *ws = workspace + MPCX_WS_HEADER_BYTES / 8;
     // (the options travel as a kernel argument: no copy from host memory, nothing to stage)
-    hipLaunchKernelGGL(mpcx_header_kernel, dim3(1), dim3(64), 0, stream, counter, d_opts, o);
+    hipLaunchKernelGGL(mpcx_header_kernel, dim3(1), dim3(1024), 0, stream, counter, d_opts, o, (unsigned)(n_waves - n_workers));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // fetch order inside the last (partial) block of 65536 problems: a multiplier coprime to its size
@@ -4053,12 +4235,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     }
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit); break;
 #else
     default: return hipErrorInvalidValue;
 #endif

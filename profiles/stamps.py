@@ -96,7 +96,7 @@ for name, col in (("start", 1), ("queue seen empty", 0), ("first extra iteration
 
 # the life of every very long problem (5000 iterations or more), from its wavefront's marks
 for w in np.nonzero(long_end[0] > 0)[0]:
-    line = f"wave {w:4d}: problem {long_end[3][w]} fetched {(long_end[2][w] - t0) / 1e8:.3f}s"
+    line = f"wave {w:4d}: problem {long_end[3][w]} fetched {(long_end[2][w] - t0) / 1e8:.3f}s" if long_end[2][w] > 0 else f"wave {w:4d}: problem {long_end[3][w]} (handed over)"
     for thr, (tm, ag) in age_marks.items():
         if tm[w] > 0:
             line += f", age {ag[w]} at {(tm[w] - t0) / 1e8:.3f}s"
@@ -106,6 +106,8 @@ for w in np.nonzero(long_end[0] > 0)[0]:
 # the wavefronts that leave last: the last problem each wrote out
 ex = marks_raw[:, 2].copy()
 ex[~used] = 0
-for w in np.argsort(-ex)[:12]:
+lo = last_out[0].copy()
+lo[~used] = 0
+for w in np.argsort(-(ex + 1e-3 * lo))[:12]:
     print(f"wave {w:4d} exit {(ex[w] - t0) / 1e8:.3f}s: last problem out at {(last_out[0][w] - t0) / 1e8:.3f}s, "
-          f"{last_out[1][w]} iterations, fetched {(last_out[2][w] - t0) / 1e8:.3f}s")
+          f"{last_out[1][w]} iterations, " + (f"fetched {(last_out[2][w] - t0) / 1e8:.3f}s" if last_out[2][w] > 0 else "handed over"))

@@ -285,6 +285,20 @@ def test_spread_recursion_leaves_no_trace(oracle, monkeypatch, spread):
         cases.assert_same_solution(gpu, ref, f"spread={spread} {name}")
 
 
+@pytest.mark.parametrize("workers", ["0", "6,64", "20,1"])
+def test_handover_leaves_no_trace(oracle, monkeypatch, workers):
+    """Old problems handed over to worker wavefronts (on by default for grids of 256 wavefronts and more; here
+    forced on a grid of 47 with 6 workers, and with 20 workers and a queue limit of one so that wavefronts also
+    keep problems for themselves) or given their bursts by the wavefront that fetched them (0): the same bits as
+    the oracle, on the benchmark distribution and on a batch where nearly every problem grows old."""
+    monkeypatch.setenv("MPCX_LANES", "64")
+    monkeypatch.setenv("MPCX_HANDOVER", workers)
+    for name, packed in (("synthetic", synthetic_batch(3000, seed=91)), ("reachable", reachable_batch(2500, seed=92))):
+        gpu = _lib.solve_packed(packed)
+        ref = oracle.solve_packed(packed)
+        cases.assert_same_solution(gpu, ref, f"handover={workers} {name}")
+
+
 @pytest.mark.parametrize("lanes", [None, 3, 20, 64])
 def test_rti_server_matches_oracle(oracle, monkeypatch, lanes):
     """Three receding-horizon ticks of a fleet: what the device solves each tick equals the
