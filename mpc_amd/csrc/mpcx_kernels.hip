@@ -3523,6 +3523,12 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
     bool worker = born_worker;
     int job = -1;                // worker: the descriptor it is working on
     unsigned given = 0;          // slots of this wavefront whose problems are with a worker (same in all lanes)
+    // A batch where most problems grow old is better served by the wavefronts that fetched them (every hand-over
+    // is a write-back of the L2 at both ends): a wavefront hands over only while at most a quarter of the
+    // problems it has fetched have grown old, and a wavefront that was a worker from the start and has found the
+    // queue empty for 60 ms while there are still problems to fetch takes problems of its own.
+    unsigned n_got = 0, n_old = 0;
+    unsigned long long idle_since = 0;
     gdouble *const own_wave = L.wave;
     if (worker) state = LS_DONE;
     bool solo = false;           // this lane's problem lives in a region; the one-lane-per-problem sweeps skip it
@@ -3710,6 +3716,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
             }
             // the initial iterate of each new problem is laid down by the whole wavefront, a lane per stage
             const unsigned long long new_mask = __ballot(fresh);
+            n_got += (unsigned)__popcll(new_mask);
             fresh = false;
             for (unsigned long long rest = new_mask; rest != 0; rest &= rest - 1) {
                 const int p = __ffsll((long long)rest) - 1;
@@ -3844,9 +3851,21 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
                     if (threadIdx.x == 0) MARK_LAST(22);
                     break;
                 }
+                if (born_worker && __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)B) {
+                    const unsigned long long now = wall_clock64();
+                    if (idle_since == 0) idle_since = now;
+                    else if (now - idle_since > 6000000ull) {      // 60 ms of the 100 MHz clock
+                        idle_since = 0;
+                        worker = false;
+                        if (threadIdx.x == 0) atomicAdd(ho_active, 1u);
+                        state = ((int)threadIdx.x < lanes) ? LS_FETCH : LS_DONE;
+                        continue;
+                    }
+                }
                 __builtin_amdgcn_s_sleep(127);
                 continue;
             }
+            idle_since = 0;
             // the problem moves into lane 0
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const double *d = ho_desc + (size_t)got * 32;
@@ -4002,7 +4021,8 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
                     ++n_new;
                     // (handed over while the workers keep up: with ho_limit descriptors waiting the wavefront gives
                     // the problem its bursts itself, as it would without workers)
-                    bool hand = ho != nullptr && job < 0 && slots > 0 && L.region == 0 && N < 64;
+                    ++n_old;
+                    bool hand = ho != nullptr && job < 0 && slots > 0 && L.region == 0 && N < 64 && 4u * n_old <= n_got + 64u;
                     if (hand) {
                         int waiting = 0;
                         if (threadIdx.x == 0)
