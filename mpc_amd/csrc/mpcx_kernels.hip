@@ -30,7 +30,9 @@
 //    (factors and affine substitution), whose stages are taken in turn with the algebra of
 //    one stage spread over the lanes (ric_spread); see "single-problem mode" below.
 //
-// Both modes perform the same operations in the same order for a problem.
+// Both modes perform the same operations in the same order for a problem.  On large batches the two modes
+// are also two kinds of wavefront: problems that have grown old in the first mode are handed over, through a
+// queue in the workspace header, to worker wavefronts that do nothing but the second (see the kernel).
 //
 // The problem is the one reference src/core_solver.py:127-351 poses and hands
 // to acados at :354/:502; the algorithm is the one its options block :242-253
