@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 107
+#define MPCX_VERSION 108
 
 #define MPCX_NX 5       /* state  [x, y, theta, v, delta]        (core_solver.py:131) */
 #define MPCX_NU 2       /* input  [acceleration, steering rate]  (core_solver.py:132) */
@@ -74,6 +74,23 @@ typedef struct mpcx_batch {
     const double  *uguess;  /* [N][2][B] initial input guess, or NULL = zeros, which is what the
                                reference starts from (it never sets "u"); used by receding-
                                horizon callers that shift the previous solution              */
+    const int32_t *order;   /* [B] a permutation of 0..B-1, or NULL.  The order in which the GPU's
+                               wavefronts TAKE the problems: the c-th problem taken is order[c].
+                               Results are written at the problem's own index and do not depend on it
+                               (bit for bit); the time of a large batch does, because a problem of ten
+                               thousand iterations that is taken last ends long after everything else.
+                               A caller who knows which problems are long (the qp_iter of an earlier
+                               solve of the same or a similar batch: the last tick of a receding-horizon
+                               loop, the last point of a sweep) puts them first — 64 entries apart: a
+                               wavefront takes 64 consecutive entries at a time, and long problems that
+                               share a wavefront wait for each other.  NULL = the library's
+                               own order (blocks of 65 536 in the caller's order, scattered inside a
+                               block).  An entry outside 0..B-1 names no problem and is skipped; a
+                               problem named twice is solved twice (same bits), one named nowhere keeps
+                               whatever its result rows held.  mpcx_solve_batch and mpcx_ctx_solve check
+                               the permutation on the host (MPCX_E_BADARG); the device entry points
+                               cannot.  No counterpart in the reference, which solves one problem a
+                               call.                                                            */
 } mpcx_batch;
 
 /* Per-problem status, acados numbering as seen by core_solver.py:502-507. */

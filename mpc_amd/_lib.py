@@ -19,7 +19,7 @@ c_int32_p = C.POINTER(C.c_int32)
 class MpcxBatch(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32),
                 ("pdata", C.c_void_p), ("n_obs", C.c_void_p), ("xguess", C.c_void_p),
-                ("uguess", C.c_void_p)]
+                ("uguess", C.c_void_p), ("order", C.c_void_p)]
 
 
 class MpcxOpts(C.Structure):
@@ -136,7 +136,8 @@ def alloc_result(B, N):
 
 
 def batch_struct(packed):
-    """mpcx_batch over the host arrays of a PackedBatch (xguess None = NULL: the library's guess)."""
+    """mpcx_batch over the host arrays of a PackedBatch (xguess None = NULL: the library's guess;
+    order None = NULL: the library's own fetch order)."""
     assert packed.pdata.flags.c_contiguous and packed.pdata.dtype == np.float64
     assert packed.pdata.shape == (MPCX_NFIELDS, packed.B)
     assert packed.n_obs.flags.c_contiguous and packed.n_obs.dtype == np.int32
@@ -146,9 +147,13 @@ def batch_struct(packed):
     ug = getattr(packed, "uguess", None)
     if ug is not None:
         assert ug.flags.c_contiguous and ug.dtype == np.float64 and ug.shape == (packed.N, 2, packed.B)
+    order = getattr(packed, "order", None)
+    if order is not None:
+        assert order.flags.c_contiguous and order.dtype == np.int32 and order.shape == (packed.B,)
     return MpcxBatch(packed.B, packed.N, packed.pdata.ctypes.data,
                      packed.n_obs.ctypes.data, xg.ctypes.data if xg is not None else None,
-                     ug.ctypes.data if ug is not None else None)
+                     ug.ctypes.data if ug is not None else None,
+                     order.ctypes.data if order is not None else None)
 
 
 def result_struct(out):

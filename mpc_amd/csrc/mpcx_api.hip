@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "../../include/mpcx.h"
 #include "mpcx_kernels.h"
@@ -172,6 +173,19 @@ int check_call(const mpcx_batch *in, const mpcx_opts *o, const mpcx_result *out)
     return 0;
 }
 
+// a caller's fetch order in HOST memory: a permutation of 0..B-1
+int check_order(const int32_t *order, size_t B)
+{
+    std::vector<unsigned char> seen(B, 0);
+    for (size_t c = 0; c < B; ++c) {
+        const int32_t b = order[c];
+        if (b < 0 || (size_t)b >= B) return fail(MPCX_E_BADARG, "order[%zu] = %d outside [0, %zu)", c, b, B);
+        if (seen[(size_t)b]) return fail(MPCX_E_BADARG, "order names problem %d twice (second time at %zu)", b, c);
+        seen[(size_t)b] = 1;
+    }
+    return 0;
+}
+
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -208,7 +222,7 @@ struct Grow {
 struct mpcx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    Grow pd, no, xg, ug, X, U, st, si, qi, co, re, ws, stats;      // device
+    Grow pd, no, xg, ug, ord, X, U, st, si, qi, co, re, ws, stats;      // device
     Grow hX, hU, hst, hsi, hqi, hco, hre, hstats;                  // page-locked host
     mpcx_ctx() { hX.host = hU.host = hst.host = hsi.host = hqi.host = hco.host = hre.host = hstats.host = true; }
 };
@@ -333,6 +347,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     }
     if (o.max_obs >= 0 && o.max_obs < nh) return fail(MPCX_E_BADARG, "max_obs %d < largest n_obs %d", o.max_obs, nh);
     o.max_obs = nh;
+    if (in->order) if (int rc = check_order(in->order, B)) return rc;
 
     const size_t n_pd = (size_t)MPCX_NFIELDS * B, n_xg = in->xguess ? (N + 1) * MPCX_NX * B : 0;
     const size_t n_X = B * (N + 1) * MPCX_NX, n_U = B * N * MPCX_NU;
@@ -367,6 +382,11 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
         if (d_ug.alloc(n_U * 8) != hipSuccess) { (void)hipGetLastError(); return fail(MPCX_E_NOMEM, "device allocation failed"); }
         HIP_TRY(hipMemcpy(d_ug.p, in->uguess, n_U * 8, hipMemcpyHostToDevice));
     }
+    DevBuf d_or;
+    if (in->order) {
+        if (d_or.alloc(B * 4) != hipSuccess) { (void)hipGetLastError(); return fail(MPCX_E_NOMEM, "device allocation failed"); }
+        HIP_TRY(hipMemcpy(d_or.p, in->order, B * 4, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemset(d_st.p, 0xff, B * 4));
 
     mpcx_batch din = *in;
@@ -374,6 +394,7 @@ int mpcx_solve_batch(const mpcx_batch *in, const mpcx_opts *opts, mpcx_result *o
     din.n_obs = d_no.as<int32_t>();
     din.xguess = in->xguess ? d_xg.as<double>() : nullptr;
     din.uguess = in->uguess ? d_ug.as<double>() : nullptr;
+    din.order = in->order ? d_or.as<int32_t>() : nullptr;
     mpcx_result dout;
     dout.X = d_X.as<double>();
     dout.U = d_U.as<double>();
@@ -480,7 +501,7 @@ void mpcx_ctx_destroy(mpcx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    Grow *all[] = {&c->pd, &c->no, &c->xg, &c->ug, &c->X, &c->U, &c->st, &c->si, &c->qi, &c->co, &c->re, &c->ws,
+    Grow *all[] = {&c->pd, &c->no, &c->xg, &c->ug, &c->ord, &c->X, &c->U, &c->st, &c->si, &c->qi, &c->co, &c->re, &c->ws,
                    &c->stats, &c->hX, &c->hU, &c->hst, &c->hsi, &c->hqi, &c->hco, &c->hre, &c->hstats};
     for (Grow *g : all) g->release();
     delete c;
@@ -508,6 +529,7 @@ int mpcx_ctx_solve(mpcx_ctx *c, const mpcx_batch *in, const mpcx_opts *opts, mpc
     }
     if (o.max_obs >= 0 && o.max_obs < nh) return fail(MPCX_E_BADARG, "max_obs %d < largest n_obs %d", o.max_obs, nh);
     o.max_obs = nh;
+    if (in->order) if (int rc = check_order(in->order, B)) return rc;
 
     const char *stage_env = std::getenv("MPCX_CTX_STAGE");
     const bool staged = stage_env && std::atoi(stage_env) != 0;
@@ -515,7 +537,7 @@ int mpcx_ctx_solve(mpcx_ctx *c, const mpcx_batch *in, const mpcx_opts *opts, mpc
     const size_t n_X = B * (N + 1) * MPCX_NX, n_U = B * N * MPCX_NU;
     // buffers: kept from the last call where large enough (at least one byte each, so B = 0 yields valid pointers)
     struct { Grow *g; size_t bytes; } need[] = {
-        {&c->pd, n_pd * 8}, {&c->no, B * 4}, {&c->xg, n_xg * 8}, {&c->ug, in->uguess ? n_U * 8 : 0},
+        {&c->pd, n_pd * 8}, {&c->no, B * 4}, {&c->xg, n_xg * 8}, {&c->ug, in->uguess ? n_U * 8 : 0}, {&c->ord, in->order ? B * 4 : 0},
         {&c->X, staged ? n_X * 8 : 0}, {&c->U, staged ? n_U * 8 : 0}, {&c->st, B * 4}, {&c->si, B * 4}, {&c->qi, B * 4}, {&c->co, B * 8},
         {&c->re, 4 * B * 8}, {&c->stats, MPCX_NSTATS * 8},
         {&c->hX, n_X * 8}, {&c->hU, n_U * 8}, {&c->hst, B * 4}, {&c->hsi, B * 4}, {&c->hqi, B * 4}, {&c->hco, B * 8},
@@ -554,12 +576,14 @@ int mpcx_ctx_solve(mpcx_ctx *c, const mpcx_batch *in, const mpcx_opts *opts, mpc
     else HIP_TRY(hipMemsetAsync(c->no.p, 0, B * 4, q));
     if (in->xguess) HIP_TRY(hipMemcpyAsync(c->xg.p, in->xguess, n_xg * 8, hipMemcpyHostToDevice, q));
     if (in->uguess) HIP_TRY(hipMemcpyAsync(c->ug.p, in->uguess, n_U * 8, hipMemcpyHostToDevice, q));
+    if (in->order) HIP_TRY(hipMemcpyAsync(c->ord.p, in->order, B * 4, hipMemcpyHostToDevice, q));
     HIP_TRY(hipMemsetAsync(c->st.p, 0xff, B * 4, q));
     mpcx_batch din = *in;
     din.pdata = c->pd.as<double>();
     din.n_obs = c->no.as<int32_t>();
     din.xguess = in->xguess ? c->xg.as<double>() : nullptr;
     din.uguess = in->uguess ? c->ug.as<double>() : nullptr;
+    din.order = in->order ? c->ord.as<int32_t>() : nullptr;
     // X and U, the bulk of the results, are written by the kernel straight into the handle's page-locked
     // host arrays as each problem ends (page-locked memory is addressable from the device), so their
     // transfer runs under the solve instead of behind it; MPCX_CTX_STAGE=1 keeps them in device memory

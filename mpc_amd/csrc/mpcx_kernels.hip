@@ -3671,16 +3671,23 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
                 // size and near its golden-section point, so consecutive fetches lie far apart: problems
                 // that are neighbours in the caller's order (and often alike in length) end up in
                 // different wavefronts.  Results are written at the problem's own index.
+                // A caller's order (in.order) replaces all of this: the c-th fetch takes problem order[c].
                 const unsigned c = (unsigned)atomicAdd(counter, 1);
                 unsigned b = c;
-                if (deal != 0 && c < B) {
-                    const unsigned full = B & ~65535u;
-                    if (c < full) b = (c & ~65535u) | ((c * 40503u) & 65535u);
-                    else b = full + (unsigned)(((unsigned long long)(c - full) * deal) % (B - full));
+                if (c < B) {
+                    if (in.order != nullptr) {
+                        b = (unsigned)in.order[c];
+                    } else if (deal != 0) {
+                        const unsigned full = B & ~65535u;
+                        if (c < full) b = (c & ~65535u) | ((c * 40503u) & 65535u);
+                        else b = full + (unsigned)(((unsigned long long)(c - full) * deal) % (B - full));
+                    }
                 }
-                if (b >= B) {
+                if (c >= B) {
                     MARK(20);
                     state = LS_DONE;
+                } else if (b >= B) {
+                    // an entry of the caller's order that names no problem: the lane asks again next time
                 } else {
                     L.b = b;
                     L.roff = 0;

@@ -27,12 +27,12 @@ def test_exports_match_header():
             "mpcx_max_horizon"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mpcx.h but not exported"
-    assert lib.mpcx_version() == 107
+    assert lib.mpcx_version() == 108
 
 
 def test_struct_layout_and_defaults():
     o = _lib.default_opts()
-    assert C.sizeof(_lib.MpcxOpts) == 176 and C.sizeof(_lib.MpcxBatch) == 40 and C.sizeof(_lib.MpcxResult) == 56
+    assert C.sizeof(_lib.MpcxOpts) == 176 and C.sizeof(_lib.MpcxBatch) == 48 and C.sizeof(_lib.MpcxResult) == 56
     assert (o.max_sqp_iter, o.max_qp_iter, o.tol_stat, o.lm) == (200, 50, 1e-3, 1e-2)   # core_solver.py:246-252
     assert (o.qp_tol_stat, o.qp_tol_eq, o.qp_tol_ineq, o.qp_tol_comp, o.lm_scale_by_h) == (1e-6, 1e-8, 1e-8, 1e-6, 1)
     assert (o.mu0, o.thr0, o.cond_pred_corr, o.rti, o.max_obs) == (10.0, 0.1, 1, 0, -1)

@@ -132,6 +132,80 @@ def test_fetch_order_leaves_no_trace(oracle, monkeypatch):
     cases.assert_same_solution(dealt, ref, f"synthetic B={B}")
 
 
+def test_callers_order_leaves_no_trace(oracle):
+    """mpcx_batch.order: the problems taken back to front, in a random order and longest first (from the
+    iteration counts of the first solve) give the results of the library's own order, the oracle's, at
+    every problem's own index; through the solver handle as well."""
+    import dataclasses
+    from mpc_amd.batch import longest_first
+    B = 20000
+    packed = synthetic_batch(B)
+    base = _lib.solve_packed(packed)
+    rng = np.random.default_rng(3)
+    orders = {"back to front": np.arange(B - 1, -1, -1, dtype=np.int32),
+              "random": np.ascontiguousarray(rng.permutation(B), dtype=np.int32),
+              "longest first": longest_first(base["qp_iter"])}
+    lf = orders["longest first"]
+    assert sorted(lf.tolist()) == list(range(B)) and base["qp_iter"][lf[0]] == base["qp_iter"].max()
+    for name, order in orders.items():
+        other = _lib.solve_packed(dataclasses.replace(packed, order=order))
+        cases.assert_same_solution(base, other, f"order {name} vs the library's")
+    with _lib.Context() as ctx:
+        other = ctx.solve(dataclasses.replace(packed, order=orders["random"]))
+        cases.assert_same_solution(base, other, "order random through the handle")
+    ref = oracle.solve_packed(packed)
+    cases.assert_same_solution(base, ref, f"synthetic B={B}")
+
+
+def test_callers_order_is_checked():
+    """An order that is no permutation is refused by the host entry points; the device entry point cannot
+    check and skips entries that name no problem: the problems named are solved, the others' rows untouched."""
+    import dataclasses
+    import torch
+    B = 300
+    packed = synthetic_batch(B)
+    twice = np.arange(B, dtype=np.int32); twice[7] = 8
+    with pytest.raises(_lib.MpcxError, match="twice"):
+        _lib.solve_packed(dataclasses.replace(packed, order=twice))
+    outside = np.arange(B, dtype=np.int32); outside[0] = B
+    with pytest.raises(_lib.MpcxError, match="outside"):
+        _lib.solve_packed(dataclasses.replace(packed, order=outside))
+    with _lib.Context() as ctx, pytest.raises(_lib.MpcxError, match="outside"):
+        ctx.solve(dataclasses.replace(packed, order=outside))
+
+    base = _lib.solve_packed(packed)
+    lib = _lib.load_library()
+    dev = torch.device("cuda:0")
+    order = np.arange(B, dtype=np.int32)[::-1].copy()
+    skipped = [5, 64, 299]
+    for i, b in enumerate(skipped):
+        order[B - 1 - b] = (-1, B, 2 ** 31 - 1)[i]
+    d_pd, d_no, d_or = (torch.from_numpy(a).to(dev) for a in (packed.pdata, packed.n_obs, order))
+    N = packed.N
+    out = {"X": torch.full((B, N + 1, 5), 7.0, dtype=torch.float64, device=dev),
+           "U": torch.full((B, N, 2), 7.0, dtype=torch.float64, device=dev),
+           "status": torch.full((B,), -5, dtype=torch.int32, device=dev),
+           "sqp_iter": torch.zeros(B, dtype=torch.int32, device=dev), "qp_iter": torch.zeros(B, dtype=torch.int32, device=dev),
+           "cost": torch.zeros(B, dtype=torch.float64, device=dev), "res": torch.zeros((4, B), dtype=torch.float64, device=dev)}
+    ws_bytes = lib.mpcx_workspace_bytes(B, N)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    d_xg = None if packed.xguess is None else torch.from_numpy(packed.xguess).to(dev)
+    bs = _lib.MpcxBatch(B, N, d_pd.data_ptr(), d_no.data_ptr(), None if d_xg is None else d_xg.data_ptr(), None,
+                        d_or.data_ptr())
+    rs = _lib.MpcxResult(*(out[k].data_ptr() for k in ("X", "U", "status", "sqp_iter", "qp_iter", "cost", "res")))
+    opts = _lib.default_opts(lib)
+    opts.max_obs = 0
+    rc = lib.mpcx_solve_batch_device(C.byref(bs), C.byref(opts), C.byref(rs), ws.data_ptr(), ws_bytes, None)
+    assert rc == 0, lib.mpcx_last_error()
+    torch.cuda.synchronize()
+    status = out["status"].cpu().numpy()
+    named = np.setdiff1d(np.arange(B), skipped)
+    assert (status[skipped] == -5).all() and (out["X"][skipped] == 7.0).all()
+    assert np.array_equal(status[named], base["status"][named])
+    assert np.array_equal(out["X"].cpu().numpy()[named], base["X"][named])
+    assert np.array_equal(out["U"].cpu().numpy()[named], base["U"][named])
+
+
 @pytest.mark.parametrize("hold", ["0,0", "0.5,8", "1e-3,1000"])
 def test_hold_policy_leaves_no_trace(oracle, monkeypatch, hold):
     """Which problems are aged into single-problem mode is scheduling only: no ageing hold (0,0), a hold
