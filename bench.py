@@ -63,8 +63,9 @@ def parse_args(argv=None):
                     help="third workload: goals reached by a random admissible input sequence (about 95 %% converge)")
     ap.add_argument("--host-guess", action="store_true",
                     help="upload the host's initial guess instead of letting the kernel compute it")
-    ap.add_argument("--order-threshold", type=int, default=300,
-                    help="the callers_order block moves problems of this many interior-point iterations or more to the front")
+    ap.add_argument("--order-threshold", type=int, default=0,
+                    help="the callers_order block moves problems of this many interior-point iterations or more to the front "
+                         "(0: the whole batch sorted by iteration count)")
     ap.add_argument("--order", default=None, help="experiment: permute the batch before upload (align | counts:FILE | reverse; +deal)")
     ap.add_argument("--lib", default=None, help="another build of the library (diagnostic builds)")
     ap.add_argument("--cpu-sample", type=int, default=262144, help="problems timed on the CPU oracle (0 = skip)")
@@ -424,9 +425,10 @@ def main():
         from mpc_amd.batch import longest_first
         order = longest_first(qp_it, threshold=args.order_threshold)
         S = measure(packed, B_total, False, args.extra_steps, 1, order=order)
-        ordered = {"what": f"the headline batch once more with mpcx_batch.order = the problems that took {args.order_threshold} interior-point "
-                           "iterations or more in the solve above first, longest first, 64 entries apart (mpc_amd.batch.longest_first): what a "
-                           "caller who has solved the same or a similar batch before gets; not the headline value",
+        ordered = {"what": "the headline batch once more with mpcx_batch.order = the problems sorted by the interior-point iteration "
+                           "counts of the solve above, longest first (mpc_amd.batch.longest_first"
+                           + (f", only those of {args.order_threshold} or more moved" if args.order_threshold > 0 else "")
+                           + "): what a caller who has solved the same or a similar batch before gets; not the headline value",
                    "moved_to_the_front": int((qp_it >= args.order_threshold).sum()),
                    "ms_per_step": 1e3 * S["elapsed"] / S["steps"], "kernel_ms": S["kernel_ms"], "steps": S["steps"], "warmup": 1,
                    "converged_per_sec": S["n_conv_all"] * S["steps"] / S["elapsed"],

@@ -74,16 +74,16 @@ typedef struct mpcx_batch {
     const double  *uguess;  /* [N][2][B] initial input guess, or NULL = zeros, which is what the
                                reference starts from (it never sets "u"); used by receding-
                                horizon callers that shift the previous solution              */
-    const int32_t *order;   /* [B] a permutation of 0..B-1, or NULL.  The order in which the GPU's
-                               wavefronts TAKE the problems: the c-th problem taken is order[c].
-                               Results are written at the problem's own index and do not depend on it
-                               (bit for bit); the time of a large batch does, because a problem of ten
-                               thousand iterations that is taken last ends long after everything else.
+    const int32_t *order;   /* [B] a permutation of 0..B-1, or NULL: the caller's PRIORITY LIST.  The
+                               GPU's wavefronts take the problems near its front first (the list is dealt
+                               over the wavefronts, which take up to 64 problems at a time, so that
+                               consecutive entries go to different wavefronts and do not wait for each
+                               other).  Results are written at the problem's own index and do not depend
+                               on it (bit for bit); the time of a large batch does, because a problem of
+                               ten thousand iterations that is taken last ends long after everything else.
                                A caller who knows which problems are long (the qp_iter of an earlier
                                solve of the same or a similar batch: the last tick of a receding-horizon
-                               loop, the last point of a sweep) puts them first — 64 entries apart: a
-                               wavefront takes 64 consecutive entries at a time, and long problems that
-                               share a wavefront wait for each other.  NULL = the library's
+                               loop, the last point of a sweep) puts them first.  NULL = the library's
                                own order (blocks of 65 536 in the caller's order, scattered inside a
                                block).  An entry outside 0..B-1 names no problem and is skipped; a
                                problem named twice is solved twice (same bits), one named nowhere keeps

@@ -48,9 +48,9 @@ class PackedBatch:
                          # reference's rules, last-bit differences in pow and arctan2, see library_guess)
     duration: float = 0.0
     uguess: np.ndarray = None    # float64 [N, 2, B] or None = zeros (the reference's start)
-    order: np.ndarray = None     # int32 [B], a permutation: the order in which the GPU takes the problems
-                                 # (long ones first, see longest_first), or None = the library's own;
-                                 # results do not depend on it
+    order: np.ndarray = None     # int32 [B], a permutation: the caller's priority list, its front is taken
+                                 # first (long problems there, see longest_first), or None = the library's
+                                 # own order; results do not depend on it
 
     def guess(self):
         """The state guess as a host array [N+1, 5, B]: the packed one, or, where the batch leaves
@@ -71,27 +71,16 @@ class PackedBatch:
         return self.take(slice(lo, hi))
 
 
-def longest_first(qp_iter, threshold=300, stride=64):
-    """A fetch order (``PackedBatch.order``) from the interior-point iteration counts of an earlier solve
-    of the same or a similar batch: the problems that took ``threshold`` iterations or more come first,
-    longest first — ``stride`` entries apart, because a wavefront takes 64 consecutive entries at a time and
-    64 long problems in one wavefront would wait for each other — and the others fill the places between
-    and behind them in the caller's order.  Only the few long problems move: the launch no longer ends
-    with a long problem that happened to be taken late."""
+def longest_first(qp_iter, threshold=0):
+    """A priority list (``PackedBatch.order``) from the interior-point iteration counts of an earlier solve
+    of the same or a similar batch: the problems that took ``threshold`` iterations or more first,
+    longest first, the others behind them in the caller's order (threshold 0: the whole batch sorted).  The
+    launch no longer ends with a long problem that happened to be taken late."""
     q = np.asarray(qp_iter)
-    B = q.shape[0]
-    idx = np.arange(B, dtype=np.int64)
+    idx = np.arange(q.shape[0], dtype=np.int64)
     long_ = idx[q >= threshold]
     long_ = long_[np.argsort(-q[long_], kind="stable")]
-    if long_.size:
-        stride = max(1, min(stride, B // long_.size))
-    at = np.arange(long_.size, dtype=np.int64) * stride
-    order = np.empty(B, dtype=np.int64)
-    taken = np.zeros(B, dtype=bool)
-    taken[at] = True
-    order[at] = long_
-    order[~taken] = idx[q < threshold]
-    return np.ascontiguousarray(order, dtype=np.int32)
+    return np.ascontiguousarray(np.concatenate([long_, idx[q < threshold]]), dtype=np.int32)
 
 
 # ---------------------------------------------------------------------------

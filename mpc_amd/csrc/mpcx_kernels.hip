@@ -3671,12 +3671,19 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
                 // size and near its golden-section point, so consecutive fetches lie far apart: problems
                 // that are neighbours in the caller's order (and often alike in length) end up in
                 // different wavefronts.  Results are written at the problem's own index.
-                // A caller's order (in.order) replaces all of this: the c-th fetch takes problem order[c].
+                // A caller's order (in.order) replaces all of this.  It is a priority list: its front is taken
+                // first, and since a wavefront takes `lanes` consecutive tickets at a time the list is dealt so
+                // that consecutive entries go to different wavefronts: ticket c takes entry (c mod lanes) * R +
+                // c div lanes, R = B div lanes (the B mod lanes entries at the very end keep their place).  The
+                // front of the list, where a caller puts the long problems, is then spread one per wavefront
+                // instead of filling the first few wavefronts with problems that wait for each other.
                 const unsigned c = (unsigned)atomicAdd(counter, 1);
                 unsigned b = c;
                 if (c < B) {
                     if (in.order != nullptr) {
-                        b = (unsigned)in.order[c];
+                        const unsigned per = (unsigned)lanes, R = B / per;
+                        const unsigned e = (c < R * per) ? (c % per) * R + c / per : c;
+                        b = (unsigned)in.order[e];
                     } else if (deal != 0) {
                         const unsigned full = B & ~65535u;
                         if (c < full) b = (c & ~65535u) | ((c * 40503u) & 65535u);

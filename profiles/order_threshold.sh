@@ -1,4 +1,4 @@
-for t in 30 60 100 150 1000; do
+for t in 0 30 100 300 1000; do
   timeout -k 10 200 python bench.py --steps 1 --warmup 1 --extra-steps 2 --cpu-sample 0 --no-host-to-host --order-threshold $t 2>&1 | python -c "import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

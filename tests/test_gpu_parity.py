@@ -144,7 +144,9 @@ def test_callers_order_leaves_no_trace(oracle):
     rng = np.random.default_rng(3)
     orders = {"back to front": np.arange(B - 1, -1, -1, dtype=np.int32),
               "random": np.ascontiguousarray(rng.permutation(B), dtype=np.int32),
-              "longest first": longest_first(base["qp_iter"])}
+              "whole batch sorted": longest_first(base["qp_iter"]),
+              "longest first": longest_first(base["qp_iter"], threshold=300)}
+    assert (np.diff(base["qp_iter"][orders["whole batch sorted"]]) <= 0).all()
     lf = orders["longest first"]
     assert sorted(lf.tolist()) == list(range(B)) and base["qp_iter"][lf[0]] == base["qp_iter"].max()
     for name, order in orders.items():
