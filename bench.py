@@ -421,11 +421,11 @@ def main():
         torch.cuda.empty_cache()
 
     ordered = None
-    if not args.no_extra and headline_workload and not strong and world == 1 and B > 0:
+    if not args.no_extra and not (args.order or args.host_guess) and not strong and world == 1 and B > 0:
         from mpc_amd.batch import longest_first
         order = longest_first(qp_it, threshold=args.order_threshold)
         S = measure(packed, B_total, False, args.extra_steps, 1, order=order)
-        ordered = {"what": "the headline batch once more with mpcx_batch.order = the problems sorted by the interior-point iteration "
+        ordered = {"what": "the batch above once more with mpcx_batch.order = the problems sorted by the interior-point iteration "
                            "counts of the solve above, longest first (mpc_amd.batch.longest_first"
                            + (f", only those of {args.order_threshold} or more moved" if args.order_threshold > 0 else "")
                            + "): what a caller who has solved the same or a similar batch before gets; not the headline value",

@@ -64,8 +64,16 @@ class PackedBatch:
         pick = lambda a, ax: None if a is None else np.ascontiguousarray(
             a[(slice(None),) * ax + (idx,)])
         n_obs = pick(self.n_obs, 0)
+        order = None
+        if self.order is not None:
+            # the priority list restricted to the chosen problems, in its own order, in their new numbering
+            chosen = np.arange(self.B)[idx]
+            new_number = np.full(self.B, -1, dtype=np.int64)
+            new_number[chosen] = np.arange(chosen.shape[0])
+            order = new_number[self.order]
+            order = np.ascontiguousarray(order[order >= 0], dtype=np.int32)
         return PackedBatch(int(n_obs.shape[0]), self.N, pick(self.pdata, 1), n_obs,
-                           pick(self.xguess, 2), self.duration, pick(self.uguess, 2))
+                           pick(self.xguess, 2), self.duration, pick(self.uguess, 2), order)
 
     def slice(self, lo, hi):
         return self.take(slice(lo, hi))

@@ -241,6 +241,21 @@ def test_guess_left_to_the_library_is_the_host_loop():
     assert p.xguess is None and np.array_equal(p.guess()[:, :, 0], bt.initial_guess(ego, p.N))
 
 
+def test_priority_list_helpers():
+    """longest_first ranks by a previous solve's iteration counts (ties and the short problems in the
+    caller's order); a slice of a batch keeps the list restricted to its problems, renumbered."""
+    import dataclasses
+    q = np.array([5, 400, 7, 9000, 3, 400, 3, 3, 500, 2])
+    assert bt.longest_first(q).tolist() == [3, 8, 1, 5, 2, 0, 4, 6, 7, 9]
+    assert bt.longest_first(q, threshold=300).tolist() == [3, 8, 1, 5, 0, 2, 4, 6, 7, 9]
+    assert bt.longest_first(np.zeros(4)).tolist() == [0, 1, 2, 3] and bt.longest_first(np.zeros(0)).shape == (0,)
+    start, goal = random_start_goal(10, seed=3)
+    a = dataclasses.replace(bt.pack_arrays(start, goal, 5.0), order=bt.longest_first(q))
+    assert a.slice(2, 7).order.tolist() == [1, 3, 0, 2, 4] and a.slice(2, 7).order.dtype == np.int32   # problems 3, 5, 2, 4, 6
+    assert a.take(np.array([9, 3, 8])).order.tolist() == [1, 2, 0]
+    assert bt.pack_arrays(start, goal, 5.0).slice(2, 7).order is None
+
+
 def test_library_guess_with_obstacles_follows_the_reference_rules():
     """What the library computes when a batch with obstacles brings no guess (restated in numpy,
     batch.library_guess): the reference's rules -- line shifted past a straddling obstacle, points
