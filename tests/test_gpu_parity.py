@@ -366,10 +366,15 @@ def test_handover_leaves_no_trace(oracle, monkeypatch, workers):
     """Old problems handed over to worker wavefronts (on by default for grids of 256 wavefronts and more; here
     forced on a grid of 47 with 6 workers, and with 20 workers and a queue limit of one so that wavefronts also
     keep problems for themselves) or given their bursts by the wavefront that fetched them (0): the same bits as
-    the oracle, on the benchmark distribution and on a batch where nearly every problem grows old."""
+    the oracle, on the benchmark distribution, on a batch where nearly every problem grows old, and with
+    obstacle rows (up to 4, 2 and 1 per problem) at horizons of 50, 20 and 62 intervals."""
     monkeypatch.setenv("MPCX_LANES", "64")
     monkeypatch.setenv("MPCX_HANDOVER", workers)
-    for name, packed in (("synthetic", synthetic_batch(3000, seed=91)), ("reachable", reachable_batch(2500, seed=92))):
+    batches = [("synthetic", synthetic_batch(3000, seed=91)), ("reachable", reachable_batch(2500, seed=92))]
+    for duration, k in ((5.0, 4), (2.0, 2), (6.3, 1)):
+        packed = pack_problems(*cases.obstacle_problems(1500, duration, seed=60 + k, max_obs=k))
+        batches.append((f"up to {k} obstacles, N={packed.N}", packed))
+    for name, packed in batches:
         gpu = _lib.solve_packed(packed)
         ref = oracle.solve_packed(packed)
         cases.assert_same_solution(gpu, ref, f"handover={workers} {name}")
