@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402,F401  one HIP runtime per process
 import oracle_lib  # noqa: E402
 from mpc_amd import _lib  # noqa: E402
+from mpc_amd.batch import longest_first  # noqa: E402
 from mpc_amd.synthetic import reachable_batch, synthetic_batch  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
@@ -23,7 +24,7 @@ threads = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_T
 fast = oracle_lib.load(oracle_lib.ORACLE_FAST_SO if os.path.exists(oracle_lib.ORACLE_FAST_SO) else oracle_lib.ORACLE_SO)
 
 
-def compare(name, packed, opts=None, oopts=None):
+def compare(name, packed, opts=None, oopts=None, with_order=True):
     t0 = time.time()
     gpu = _lib.solve_packed(packed, opts=opts)
     t1 = time.time()
@@ -37,6 +38,14 @@ def compare(name, packed, opts=None, oopts=None):
     print(f"{name:44s} B={packed.B:8d}  identical={same}  status mix {mix.tolist()}  "
           f"IP iterations {int(ref['qp_iter'].sum())}  device {t1 - t0:.1f} s  oracle {t2 - t1:.1f} s ({threads} threads)")
     sys.stdout.flush()
+    if with_order:
+        # once more with the caller's priority list (the batch ranked by these iteration counts)
+        import dataclasses
+        again = _lib.solve_packed(dataclasses.replace(packed, order=longest_first(ref["qp_iter"])), opts=opts)
+        same2 = all(np.array_equal(again[k], gpu[k]) for k in ("status", "sqp_iter", "qp_iter", "X", "U", "cost", "res"))
+        print(f"{'  the same with mpcx_batch.order':44s} B={packed.B:8d}  identical={same2}")
+        sys.stdout.flush()
+        same = same and same2
     return same
 
 
