@@ -3283,7 +3283,7 @@ template <int NH>
 __global__ void __launch_bounds__(64) __attribute__((disable_tail_calls))
 mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, double *workspace, int *counter, int lanes, int coop_max, int lin_max, int svc_min,
                 int boost_min, int boost_div, int boost_cap, int boost_lanes, int coop_layout, int slots, unsigned deal, int burst_few,
-                double hold_alpha, int hold_extra, int boost_mul, int spread_on, unsigned char *ho, int n_workers, int ho_limit)
+                double hold_alpha, int hold_extra, int boost_mul, int spread_on, unsigned char *ho, int n_workers, int ho_limit, int ho_late)
 {
     const mpcx_opts &o = *op_generic;
     gopts *op = (gopts *)op_generic;      // what the sweeps are handed
@@ -4012,6 +4012,45 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
         if (boost_div > 0 && !o.rti) {
             int budget = boost_cap, n_new = 0;
             unsigned long long seen = 0;
+            // hand-over: is there room in the queue; and the hand-over itself of lane p's problem, which lies in
+            // region `slot` of this wavefront
+            auto queue_has_room = [&]() -> bool {
+                int waiting = 0;
+                if (threadIdx.x == 0)
+                    waiting = (int)(__hip_atomic_load(ho_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                                    __hip_atomic_load(ho_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                return __builtin_amdgcn_readfirstlane(waiting) < ho_limit;
+            };
+            auto give_away = [&](int p, int slot) {
+                const int id = (int)blockIdx.x * slots + slot;
+                if ((int)threadIdx.x == p) {
+                    double *d = ho_desc + (size_t)id * 32;
+                    d[0] = (double)L.b; d[1] = (double)L.nobs; d[2] = (double)state; d[3] = (double)status;
+                    d[4] = (double)sqp_it; d[5] = (double)qp_it; d[6] = (double)qp_total; d[7] = (double)m_total;
+                    d[8] = first ? 1.0 : 0.0; d[9] = sp.have ? 1.0 : 0.0; d[10] = (double)sp.mode;
+                    d[11] = sp.sigma_mu; d[12] = sp.alpha;
+                    d[13] = res[0]; d[14] = res[1]; d[15] = res[2]; d[16] = res[3];
+                    d[17] = cost; d[18] = ls_rho; d[19] = (double)L.roff; d[20] = (double)blockIdx.x;
+                    __hip_atomic_store(ho_busy + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if ((int)threadIdx.x == p) {
+                    const unsigned t = atomicAdd(ho_tail, 1u);
+                    __hip_atomic_store(ho_ring + (t & (MPCX_HANDOVER_SLOTS - 1)), (unsigned)id + 1u, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    // the lane is free; the region stays taken until the worker is done with it
+                    state = LS_FETCH;
+                    solo = false;
+                    L.roff = 0;
+                }
+                given |= 1u << slot;
+            };
+            // A problem the wavefront kept for itself (the queue was full, or most of its problems grow old) is
+            // offered again: once it is ho_late iterations old -- its bursts, which grow with its age, hold up the
+            // wavefront's other problems -- and, when there is nothing left to fetch, whenever the wavefront has
+            // more than one such problem: the wavefronts that are done are workers by then.
+            const bool late_on = ho != nullptr && ho_late > 0 && job < 0 && slots > 0 && L.region == 0 && N < 64;
+            const bool fetch_over = late_on && __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)B;
             for (;;) {
                 const int age = qp_total + ((state == LS_QP) ? qp_it : 0);
                 const bool live = ((state == LS_QP) || (state == LS_LIN)) && !((seen >> threadIdx.x) & 1ull);
@@ -4027,6 +4066,12 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
                 if (sm != 0) {
                     p = __ffsll((long long)sm) - 1;
                     best = __builtin_amdgcn_readlane(age, p);
+                    if (late_on && (best >= ho_late || (fetch_over && __popcll(sm) >= 2)) && queue_has_room()) {
+                        const unsigned r = (unsigned)__builtin_amdgcn_readlane((int)L.roff, p);
+                        give_away(p, (int)((r / rec_bytes - (unsigned)(N + 1)) / nblk));
+                        seen |= 1ull << p;
+                        continue;
+                    }
                 } else {
                     if (budget <= 0) break;
                     for (unsigned long long rest = cm; rest != 0; rest &= rest - 1) {
@@ -4039,13 +4084,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
                     // the problem its bursts itself, as it would without workers)
                     ++n_old;
                     bool hand = ho != nullptr && job < 0 && slots > 0 && L.region == 0 && N < 64 && 4u * n_old <= n_got + 64u;
-                    if (hand) {
-                        int waiting = 0;
-                        if (threadIdx.x == 0)
-                            waiting = (int)(__hip_atomic_load(ho_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                                            __hip_atomic_load(ho_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        hand = __builtin_amdgcn_readfirstlane(waiting) < ho_limit;
-                    }
+                    if (hand) hand = queue_has_room();
                     if (hand) {
                         // regions whose problems a worker has finished are free again
                         if (given != 0) {
@@ -4059,29 +4098,7 @@ mpcx_sqp_kernel(mpcx_batch in, const mpcx_opts *op_generic, mpcx_result out, dou
                         }
                         const unsigned before = slot_used;
                         if (move_to_region(p) && slot_used != before) {
-                            const int slot = __ffs((int)(slot_used & ~before)) - 1;
-                            const int id = (int)blockIdx.x * slots + slot;
-                            if ((int)threadIdx.x == p) {
-                                double *d = ho_desc + (size_t)id * 32;
-                                d[0] = (double)L.b; d[1] = (double)L.nobs; d[2] = (double)state; d[3] = (double)status;
-                                d[4] = (double)sqp_it; d[5] = (double)qp_it; d[6] = (double)qp_total; d[7] = (double)m_total;
-                                d[8] = first ? 1.0 : 0.0; d[9] = sp.have ? 1.0 : 0.0; d[10] = (double)sp.mode;
-                                d[11] = sp.sigma_mu; d[12] = sp.alpha;
-                                d[13] = res[0]; d[14] = res[1]; d[15] = res[2]; d[16] = res[3];
-                                d[17] = cost; d[18] = ls_rho; d[19] = (double)L.roff; d[20] = (double)blockIdx.x;
-                                __hip_atomic_store(ho_busy + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                            if ((int)threadIdx.x == p) {
-                                const unsigned t = atomicAdd(ho_tail, 1u);
-                                __hip_atomic_store(ho_ring + (t & (MPCX_HANDOVER_SLOTS - 1)), (unsigned)id + 1u, __ATOMIC_RELEASE,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-                                // the lane is free; the region stays taken until the worker is done with it
-                                state = LS_FETCH;
-                                solo = false;
-                                L.roff = 0;
-                            }
-                            given |= 1u << slot;
+                            give_away(p, __ffs((int)(slot_used & ~before)) - 1);
                             seen |= 1ull << p;
                             continue;
                         }
@@ -4231,11 +4248,13 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     // problems (large batches) with bursts available; 5/16 of the wavefronts are workers from the start, and a
     // wavefront keeps an old problem for itself while 64 descriptors wait (measured on 1 M problems: 128..512
     // workers, limits 16..2048; the reachable and obstacle workloads and 131 072 / 262 144 problems beside the
-    // benchmark batch).  MPCX_HANDOVER="workers[,limit]" sets both, 0 switches the hand-over off.
-    int n_workers = (n_waves >= 256) ? (n_waves * 5) / 16 : 0, ho_limit = 64;
+    // benchmark batch).  A problem a wavefront has kept is offered again from ho_late iterations on, and at the
+    // end of the launch (see the kernel).  MPCX_HANDOVER="workers[,limit[,late]]" sets them, workers 0 switches
+    // the hand-over off, late 0 the second offer.
+    int n_workers = (n_waves >= 256) ? (n_waves * 5) / 16 : 0, ho_limit = 64, ho_late = 128;
     if (const char *e = getenv("MPCX_HANDOVER")) {      // (also on smaller grids: the tests)
-        int v = 0, l = 64;
-        if (sscanf(e, "%d,%d", &v, &l) >= 1 && v >= 0 && v < n_waves && l >= 1) { n_workers = v; ho_limit = l; }
+        int v = 0, l = 64, a = 128;
+        if (sscanf(e, "%d,%d,%d", &v, &l, &a) >= 1 && v >= 0 && v < n_waves && l >= 1 && a >= 0) { n_workers = v; ho_limit = l; ho_late = a; }
     }
     const bool handover = n_workers > 0 && lanes == 64 && !o.rti && in.N < 64 && burst_few > 0 &&
                           n_waves * slots <= MPCX_HANDOVER_SLOTS && coop_layout == 0 && coop_max > 0 && slots > 0;
@@ -4271,12 +4290,12 @@ hipError_t mpcx_launch_sqp(int nh, const mpcx_batch &in, const mpcx_opts &o, con
     }
     dim3 grid(n_waves), block(64);
     switch (nh) {
-    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit); break;
+    case 0: hipLaunchKernelGGL(mpcx_sqp_kernel<0>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit, ho_late); break;
 #ifndef MPCX_DEV_ONLY_NH0   /* development builds compile one instantiation only */
-    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit); break;
-    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit); break;
-    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit); break;
-    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit); break;
+    case 1: hipLaunchKernelGGL(mpcx_sqp_kernel<1>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit, ho_late); break;
+    case 2: hipLaunchKernelGGL(mpcx_sqp_kernel<2>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit, ho_late); break;
+    case 3: hipLaunchKernelGGL(mpcx_sqp_kernel<3>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit, ho_late); break;
+    default: hipLaunchKernelGGL(mpcx_sqp_kernel<4>, grid, block, 0, stream, in, d_opts, out, ws, counter, lanes, coop_max, lin_max, svc_min, boost_min, boost_div, boost_cap, boost_lanes, coop_layout, slots, deal, burst_few, hold_alpha, hold_extra, boost_mul, spread_on, ho, n_workers, ho_limit, ho_late); break;
 #else
     default: return hipErrorInvalidValue;
 #endif
