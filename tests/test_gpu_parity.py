@@ -361,11 +361,12 @@ def test_spread_recursion_leaves_no_trace(oracle, monkeypatch, spread):
         cases.assert_same_solution(gpu, ref, f"spread={spread} {name}")
 
 
-@pytest.mark.parametrize("workers", ["0", "6,64", "20,1"])
+@pytest.mark.parametrize("workers", ["0", "6,64", "20,1", "12,2,16"])
 def test_handover_leaves_no_trace(oracle, monkeypatch, workers):
     """Old problems handed over to worker wavefronts (on by default for grids of 256 wavefronts and more; here
     forced on a grid of 47 with 6 workers, and with 20 workers and a queue limit of one so that wavefronts also
-    keep problems for themselves) or given their bursts by the wavefront that fetched them (0): the same bits as
+    keep problems for themselves, and with kept problems offered again from 16 iterations on instead of 128)
+    or given their bursts by the wavefront that fetched them (0): the same bits as
     the oracle, on the benchmark distribution, on a batch where nearly every problem grows old, and with
     obstacle rows (up to 4, 2 and 1 per problem) at horizons of 50, 20 and 62 intervals."""
     monkeypatch.setenv("MPCX_LANES", "64")
