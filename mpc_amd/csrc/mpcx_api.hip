@@ -11,8 +11,8 @@
 #include <atomic>
 #include <cstring>
 #include <mutex>
+#include <memory>
 #include <new>
-#include <vector>
 
 #include "../../include/mpcx.h"
 #include "mpcx_kernels.h"
@@ -176,7 +176,9 @@ int check_call(const mpcx_batch *in, const mpcx_opts *o, const mpcx_result *out)
 // a caller's fetch order in HOST memory: a permutation of 0..B-1
 int check_order(const int32_t *order, size_t B)
 {
-    std::vector<unsigned char> seen(B, 0);
+    // (no exception may cross the C boundary)
+    std::unique_ptr<unsigned char[]> seen(new (std::nothrow) unsigned char[B ? B : 1]());
+    if (!seen) return fail(MPCX_E_NOMEM, "no memory to check the order (%zu bytes)", B);
     for (size_t c = 0; c < B; ++c) {
         const int32_t b = order[c];
         if (b < 0 || (size_t)b >= B) return fail(MPCX_E_BADARG, "order[%zu] = %d outside [0, %zu)", c, b, B);
