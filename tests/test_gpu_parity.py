@@ -132,12 +132,16 @@ def test_fetch_order_leaves_no_trace(oracle, monkeypatch):
     cases.assert_same_solution(dealt, ref, f"synthetic B={B}")
 
 
-def test_callers_order_leaves_no_trace(oracle):
+@pytest.mark.parametrize("lanes", [None, "64"])
+def test_callers_order_leaves_no_trace(oracle, monkeypatch, lanes):
     """mpcx_batch.order: the problems taken back to front, in a random order and longest first (from the
     iteration counts of the first solve) give the results of the library's own order, the oracle's, at
-    every problem's own index; through the solver handle as well."""
+    every problem's own index; through the solver handle as well.  With one problem at a time per wavefront
+    (the list taken as it stands) and with 64 (the list dealt over the wavefronts, 32 entries left over)."""
     import dataclasses
     from mpc_amd.batch import longest_first
+    if lanes is not None:
+        monkeypatch.setenv("MPCX_LANES", lanes)
     B = 20000
     packed = synthetic_batch(B)
     base = _lib.solve_packed(packed)
